@@ -1,0 +1,175 @@
+/*
+ * sisic.h -- C ABI of libsisic_hip.so, the MI355X (gfx950) implementation of the
+ * SYNT_ISIC DDPM sampling hot path.
+ *
+ * The reference (fims9000/SYNT_ISIC) is pure Python: it has no FFI, the boundary
+ * of its hot path is duck-typing on two third-party objects
+ *     noise_pred = model(latents, t).sample                         core/generator/image_generator.py:400
+ *     latents    = scheduler.step(noise_pred, t, latents).prev_sample               image_generator.py:403
+ * built at core/generator/model_manager.py:173-194 (UNet2DModel) and :196-212
+ * (DDPMScheduler).  A maintainer of the reference binds this library with
+ * ctypes; synt_isic_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - every function returns 0 (SISIC_OK) or a negative SISIC_E* code; the message
+ *     of the last failure on the calling thread is sisic_last_error();
+ *   - "dev" pointers are device (HBM) addresses of contiguous fp32 NCHW tensors
+ *     owned by the caller (torch); the library never frees or reallocates them;
+ *   - weights are copied into a library-owned arena at load time; workspace is
+ *     library-owned per handle and grows on demand (never inside the sampling loop);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     all work is enqueued asynchronously on it unless stated otherwise;
+ *   - handles are not thread-safe; use one handle per (device, stream).
+ */
+#ifndef SISIC_H
+#define SISIC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SISIC_ABI_VERSION 1
+
+#define SISIC_OK 0
+#define SISIC_EINVAL (-1)   /* bad argument / unsupported shape */
+#define SISIC_EHIP (-2)     /* a HIP runtime call failed        */
+#define SISIC_ESTATE (-3)   /* call order violated (e.g. forward before load) */
+#define SISIC_ECANCEL (-4)  /* sampling loop stopped by the cancel flag */
+
+typedef struct sisic_ctx sisic_ctx;     /* device context: weights-independent scratch */
+typedef struct sisic_unet sisic_unet;   /* one UNet2DModel instance (weights + workspace) */
+typedef struct sisic_resnet sisic_resnet; /* one ResNet18 classifier instance */
+
+int sisic_abi_version(void);
+const char* sisic_last_error(void);
+
+/* ---- context ------------------------------------------------------------------ */
+int sisic_create(int device_id, sisic_ctx** out);
+int sisic_destroy(sisic_ctx* ctx);
+
+/* ---- single operators (parity-test surface; also what the model executor calls) -- */
+
+/* Generic NCHW fp32 convolution on the f32 MFMA pipe, replaces the F.conv2d /
+ * GroupNorm / SiLU / cat / interpolate instances inside diffusers' ResnetBlock2D,
+ * Downsample2D, Upsample2D and Attention projections.
+ *   out[b,co,y,x] = bias[co] + chan_bias[b,co] + residual[b,co,y,x]
+ *                 + sum_{ci,ky,kx} W[co,ci,ky,kx] * act(in[b,ci,...])
+ * where `in` is the channel concatenation of in0 (c0 channels) and in1 (c1 channels,
+ * may be NULL), optionally nearest-upsampled 2x, and act(v) is the optional
+ * GroupNorm-apply prologue v*gn_scale[b,ci]+gn_shift[b,ci] followed by SiLU when
+ * gn_silu != 0.  Zero padding ksize/2 is applied AFTER the prologue.            */
+typedef struct sisic_conv_args {
+    const float* in0;       /* dev [B,c0,Hin,Win]                        */
+    const float* in1;       /* dev [B,c1,Hin,Win] or NULL                */
+    int c0, c1;
+    int B, Hin, Win;
+    int upsample;           /* 1: nearest 2x before the conv              */
+    int ksize;              /* 1, 3 or 7                                  */
+    int stride;             /* 1 or 2                                     */
+    const float* w_packed;  /* dev, layout of sisic_conv_pack_weights     */
+    const float* bias;      /* dev [Cout] or NULL                         */
+    int Cout;
+    const float* gn_scale;  /* dev [B,c0+c1] or NULL (no prologue)        */
+    const float* gn_shift;  /* dev [B,c0+c1] or NULL                      */
+    int gn_silu;
+    const float* chan_bias; /* dev [B,Cout] or NULL                       */
+    int chan_bias_stride;   /* floats between samples of chan_bias; 0 = one row shared by all samples */
+    const float* residual;  /* dev [B,Cout,Hout,Wout] or NULL             */
+    int relu;               /* 1: max(0, .) after everything (classifier) */
+    float* out;             /* dev [B,Cout,Hout,Wout]                     */
+    int tile_cfg;           /* 0 = auto; >0 forces a tile configuration (tests/tuning) */
+} sisic_conv_args;
+
+/* number of floats of the packed form of an OIHW weight [Cout,Cin,k,k] */
+int64_t sisic_conv_packed_numel(int Cout, int Cin, int ksize);
+/* dev OIHW -> dev packed [Cin_pad][k*k][Cout_pad], zero padded */
+int sisic_conv_pack_weights(sisic_ctx*, const float* w_oihw, int Cout, int Cin, int ksize,
+                            float* w_packed, void* stream);
+int sisic_conv2d(sisic_ctx*, const sisic_conv_args* args, void* stream);
+
+/* GroupNorm statistics folded with the affine parameters (replaces the reduction
+ * half of torch.nn.GroupNorm inside ResnetBlock2D.norm1/norm2, Attention.group_norm
+ * and conv_norm_out):  for c in group g of sample b
+ *     scale[b,c] = gamma[c]*rstd[b,g],  shift[b,c] = beta[c] - mean[b,g]*scale[b,c].
+ * The input is the concatenation of in0/in1 as in sisic_conv_args; HW = H*W.      */
+int sisic_groupnorm_stats(sisic_ctx*, const float* in0, int c0, const float* in1, int c1,
+                          int B, int HW, int groups, float eps,
+                          const float* gamma, const float* beta,
+                          float* scale, float* shift, void* stream);
+
+/* Multi-head self-attention core (replaces scaled_dot_product_attention inside
+ * diffusers' Attention, heads = C/head_dim, softmax in fp32, scale head_dim^-0.5).
+ * qkv: dev [B,3*C,N] (q channels, then k, then v; channel = head*head_dim + d),
+ * out: dev [B,C,N].  head_dim must be 8 (the reference's attention_head_dim).     */
+int sisic_attention(sisic_ctx*, const float* qkv, float* out, int B, int C, int N, int head_dim,
+                    void* stream);
+
+/* Fused DDPMScheduler.step, elementwise over n floats:
+ *   x0 = clamp((x - sqrt_beta_prod*eps)/sqrt_alpha_prod, -clip, clip)   (clip<=0: no clamp)
+ *   out = (c0*x0 + c1*x) + sigma*z                                      (z==NULL or sigma==0: no noise)
+ * evaluated in exactly that fp32 operation order (no FMA contraction).            */
+int sisic_ddpm_step(sisic_ctx*, const float* eps, const float* x, const float* z, float* out,
+                    int64_t n, float sqrt_beta_prod, float sqrt_alpha_prod, float c0, float c1,
+                    float sigma, float clip, void* stream);
+
+/* De-normalise image_generator.py:441-447: [B,3,H,W] fp32 -> uint8 [B,H,W,3],
+ * trunc(clamp((x+1)/2,0,1)*255).                                                   */
+int sisic_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);
+
+/* ---- UNet2DModel ---------------------------------------------------------------- */
+typedef struct sisic_unet_config {
+    int in_channels, out_channels;
+    int layers_per_block;
+    int n_blocks;                    /* <= 8 */
+    int block_out_channels[8];
+    int down_attn[8];                /* 1 = AttnDownBlock2D */
+    int up_attn[8];                  /* 1 = AttnUpBlock2D   */
+    int norm_groups;
+    float norm_eps;
+    int head_dim;
+    int n_freqs;                     /* block_out_channels[0] / 2 */
+    const float* freqs;              /* host [n_freqs]: sinusoid frequencies (fp32, copied) */
+} sisic_unet_config;
+
+int sisic_unet_create(sisic_ctx*, const sisic_unet_config* cfg, sisic_unet** out);
+int sisic_unet_destroy(sisic_unet*);
+/* number / names of the tensors load expects (diffusers state_dict key order) */
+int sisic_unet_num_tensors(const sisic_unet*);
+const char* sisic_unet_tensor_name(const sisic_unet*, int index);
+/* Strict load of a flat state dict: n host pointers to contiguous fp32 tensors with
+ * the given element counts; every expected tensor must be present exactly once.    */
+int sisic_unet_load(sisic_unet*, int n, const char* const* names, const float* const* host_ptrs,
+                    const int64_t* numels);
+/* eps = model(sample, timestep).sample.  timesteps: host int64 [B] (one per sample). */
+int sisic_unet_forward(sisic_unet*, const float* sample, const int64_t* timesteps,
+                       float* out, int B, int H, int W, void* stream);
+
+/* The whole reverse-diffusion loop (image_generator.py:395-403) on one stream:
+ *   for i in 0..T-1:  eps = unet(x, t[i]);  x = ddpm_step(eps, x, z[i], coef[i])
+ * x: dev [B,C,H,W], updated in place (x_T in, x_0 out).
+ * timesteps: host int64 [T].  coef: host float [T*5] = per step
+ *   {sqrt_beta_prod, sqrt_alpha_prod, c0, c1, sigma}.
+ * noise: dev [n_noise,B,C,H,W] consumed in order by the steps with sigma != 0, or NULL.
+ * traj: dev [T,B,C,H,W] receiving x after every step, or NULL.
+ * out_u8: dev uint8 [B,H,W,C] final de-normalised image, or NULL.
+ * cancel: host int* polled between steps (non-zero stops the loop with SISIC_ECANCEL), or NULL.
+ * steps_done: host int* receiving the number of completed steps, or NULL.           */
+int sisic_sample(sisic_unet*, float* x, int B, int H, int W, int T, const int64_t* timesteps,
+                 const float* coef, float clip, const float* noise, float* traj, uint8_t* out_u8,
+                 const volatile int* cancel, int* steps_done, void* stream);
+
+/* ---- instrumentation (bench.py roofline leg) -------------------------------------- */
+/* When enabled, every conv launch is bracketed by HIP events on its own stream and
+ * accumulated per class; reading synchronises the stream.                           */
+int sisic_profile_enable(sisic_ctx*, int on);
+/* kind: 0 = conv3x3, 1 = conv1x1, 2 = groupnorm stats, 3 = attention, 4 = ddpm step,
+ *       5 = other.  Returns accumulated milliseconds, launches, algorithmic bytes, flops. */
+int sisic_profile_read(sisic_ctx*, int kind, double* ms, int64_t* launches, double* bytes, double* flops);
+int sisic_profile_reset(sisic_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SISIC_H */

@@ -1,0 +1,167 @@
+// attention.hip -- multi-head self-attention core for 32 heads x d=8 (NCHW token layout).
+//
+// Replaces scaled_dot_product_attention inside diffusers' Attention block as configured by
+// the reference (attention_head_dim=8).  The q/k/v and output
+// projections are 1x1 convolutions (conv_mfma.hip) that leave q,k,v as [B, 3C, N] with the
+// token index contiguous, so every operand here is read as contiguous rows.
+//
+// One wave owns 32 queries of one (sample, head); a workgroup (4 waves) owns 128 queries and
+// shares the head's K/V rows through LDS in blocks of 256 keys.
+//   * S^T = K^T Q on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32, 4 k-steps for d=8), computed
+//     "swapped" so the query sits on the lane and its keys in the 16 accumulator registers:
+//     the softmax row reduction is register-local plus one cross-half shuffle;
+//   * softmax in fp32, online across key blocks (exact two-pass inside a block);
+//   * P.V on the vector ALU: with d=8 the MFMA tile would be 3/4 padding, while the keys a lane
+//     holds in registers 4q..4q+3 are 4 consecutive V columns = one broadcast ds_read_b128.
+//
+// Algorithmic bytes per launch: 4*B*4*C*N (q,k,v in, o out).  FLOPs: 4*B*C*N*N.
+#include "common.h"
+
+namespace sisic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ATT_D = 8;
+constexpr int ATT_KB = 256;       // keys per LDS block
+constexpr int ATT_KT = ATT_KB / 32;
+constexpr int ATT_WAVES = 4;
+
+__global__ void __launch_bounds__(64 * ATT_WAVES)
+attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, int heads, int q_blocks,
+                 float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_D * ATT_KB];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_D * ATT_KB];
+
+    int blk = blockIdx.x;
+    const int qb = blk % q_blocks;
+    blk /= q_blocks;
+    const int head = blk % heads;
+    const int b = blk / heads;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int q0 = qb * (32 * ATT_WAVES) + wave * 32;
+    const int q = q0 + l31;
+    const bool wave_active = q0 < N;      // wave-uniform
+
+    const float* Qp = qkv + ((size_t)b * 3 * C + (size_t)head * ATT_D) * N;
+    const float* Kp = Qp + (size_t)C * N;
+    const float* Vp = Kp + (size_t)C * N;
+
+    float qreg[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qreg[s] = (q < N) ? Qp[(size_t)(2 * s + half) * N + q] : 0.0f;
+
+    float m_run = -INFINITY, l_part = 0.0f;
+    float o[ATT_D];
+#pragma unroll
+    for (int d = 0; d < ATT_D; ++d) o[d] = 0.0f;
+
+    for (int kb0 = 0; kb0 < N; kb0 += ATT_KB) {
+        __syncthreads();
+        for (int idx = tid; idx < ATT_D * ATT_KB; idx += 64 * ATT_WAVES) {
+            const int d = idx / ATT_KB, k = idx % ATT_KB;
+            const int key = kb0 + k;
+            const bool v = key < N;
+            Ks[idx] = v ? Kp[(size_t)d * N + key] : 0.0f;
+            Vs[idx] = v ? Vp[(size_t)d * N + key] : 0.0f;
+        }
+        __syncthreads();
+        if (!wave_active) continue;
+        const int nk = min(ATT_KB, N - kb0);
+
+        // pass 1: block maximum.  S^T tiles are recomputed in pass 2 instead of being kept: the MFMA
+        // pipe is otherwise idle here and 16 live accumulator registers instead of 128 keep occupancy up.
+        float mloc = -INFINITY;
+#pragma unroll 1
+        for (int kt = 0; kt < ATT_KT; ++kt) {
+            if (kt * 32 < nk) {
+                f32x16 S;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (key < nk) mloc = fmaxf(mloc, S[r] * scale);
+                }
+            }
+        }
+        const float m_blk = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, m_blk);
+        const float alpha = __expf(m_run - m_new);     // first block: exp(-inf) = 0
+        l_part *= alpha;
+#pragma unroll
+        for (int d = 0; d < ATT_D; ++d) o[d] *= alpha;
+
+        // pass 2: p = exp(s - m), row sum and P.V
+#pragma unroll 1
+        for (int kt = 0; kt < ATT_KT; ++kt) {
+            if (kt * 32 < nk) {
+                f32x16 S;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    float pv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int key = kt * 32 + 8 * rq + 4 * half + i;
+                        pv[i] = (key < nk) ? __expf(S[4 * rq + i] * scale - m_new) : 0.0f;
+                    }
+                    l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                    const int koff = kt * 32 + 8 * rq + 4 * half;
+#pragma unroll
+                    for (int d = 0; d < ATT_D; ++d) {
+                        const float4 v = *reinterpret_cast<const float4*>(&Vs[d * ATT_KB + koff]);
+                        o[d] += (pv[0] * v.x + pv[1] * v.y) + (pv[2] * v.z + pv[3] * v.w);
+                    }
+                }
+            }
+        }
+        m_run = m_new;
+    }
+
+    if (wave_active) {
+        const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+        const float inv = 1.0f / l_tot;
+        float res[ATT_D];
+#pragma unroll
+        for (int d = 0; d < ATT_D; ++d) res[d] = (o[d] + __shfl_xor(o[d], 32, 64)) * inv;
+        if (q < N) {
+            float* Op = out + ((size_t)b * C + (size_t)head * ATT_D) * N + q;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                const float v = half ? res[4 + dd] : res[dd];
+                Op[(size_t)(4 * half + dd) * N] = v;
+            }
+        }
+    }
+}
+
+int launch_attention(sisic_ctx* ctx, const float* qkv, float* out, int B, int C, int N, int head_dim, hipStream_t s) {
+    SISIC_REQUIRE(qkv && out, "attention: null tensor");
+    SISIC_REQUIRE(head_dim == ATT_D, "attention: head_dim %d unsupported (the reference uses 8)", head_dim);
+    SISIC_REQUIRE(B > 0 && N > 0 && C > 0 && C % head_dim == 0, "attention: bad shape B=%d C=%d N=%d", B, C, N);
+    const int heads = C / head_dim;
+    const int q_blocks = cdiv(N, 32 * ATT_WAVES);
+    const int64_t grid = (int64_t)B * heads * q_blocks;
+    SISIC_REQUIRE(grid < (int64_t(1) << 31), "attention: grid too large");
+    ProfileScope prof(ctx, s, PK_ATTN, 16.0 * B * C * N, 4.0 * B * C * double(N) * N);
+    const float scale = 1.0f / sqrtf((float)head_dim);
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads,
+                       q_blocks, scale);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+}  // namespace sisic

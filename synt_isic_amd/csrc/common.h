@@ -1,0 +1,107 @@
+// Internal declarations shared by the libsisic_hip.so translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/sisic.h"
+
+namespace sisic {
+
+void set_error(const char* fmt, ...);
+
+#define SISIC_HIP(call)                                                                   \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ::sisic::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),     \
+                               __FILE__, __LINE__);                                       \
+            return SISIC_EHIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define SISIC_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::sisic::set_error(__VA_ARGS__);     \
+            return SISIC_EINVAL;                 \
+        }                                        \
+    } while (0)
+
+#define SISIC_TRY(expr)             \
+    do {                            \
+        int _rc = (expr);           \
+        if (_rc != SISIC_OK) return _rc; \
+    } while (0)
+
+enum ProfileKind { PK_CONV3 = 0, PK_CONV1 = 1, PK_GN = 2, PK_ATTN = 3, PK_DDPM = 4, PK_OTHER = 5, PK_COUNT = 6 };
+
+struct ProfileSlot {
+    double ms = 0, bytes = 0, flops = 0;
+    int64_t launches = 0;
+};
+
+struct PendingEvent {
+    hipEvent_t start, stop;
+    int kind;
+};
+
+}  // namespace sisic
+
+struct sisic_ctx {
+    int device = 0;
+    int num_cus = 0;
+    bool profiling = false;
+    sisic::ProfileSlot prof[sisic::PK_COUNT];
+    std::vector<sisic::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace sisic {
+
+// RAII-less helper: brackets one launch with events when profiling is on.
+struct ProfileScope {
+    sisic_ctx* ctx;
+    hipStream_t stream;
+    PendingEvent ev{};
+    bool active = false;
+    ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops);
+    ~ProfileScope();
+};
+
+int profile_collect(sisic_ctx* ctx);
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// conv weight packing geometry (must match conv_mfma.hip)
+constexpr int CONV_CO_TILE = 64;
+inline int conv_ci_chunk(int ksize) { return ksize == 1 ? 16 : (ksize == 3 ? 8 : 4); }
+inline int conv_cin_pad(int cin, int ksize) { return round_up(cin, conv_ci_chunk(ksize)); }
+inline int conv_cout_pad(int cout) { return round_up(cout, CONV_CO_TILE); }
+
+// launchers implemented in the .hip files
+int launch_conv2d(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
+int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float* packed, hipStream_t s);
+int launch_gn_stats(sisic_ctx*, const float* in0, int c0, const float* in1, int c1, int B, int HW, int groups,
+                    float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s);
+int launch_attention(sisic_ctx*, const float* qkv, float* out, int B, int C, int N, int head_dim, hipStream_t s);
+int launch_ddpm_step(sisic_ctx*, const float* eps, const float* x, const float* z, float* out, int64_t n,
+                     float sb, float sa, float c0, float c1, float sigma, float clip, hipStream_t s);
+int launch_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
+// time embedding: sinusoid -> linear1 -> SiLU -> linear2 -> SiLU  (weights transposed [in][out])
+int launch_temb_mlp(sisic_ctx*, const float* t_vals, int B, const float* freqs, int n_freqs, const float* w1t,
+                    const float* b1, const float* w2t, const float* b2, int hidden, float* temb_act, hipStream_t s);
+// out[b, r] = sum_k wt[k][r] * x[b][k] + bias[r]
+int launch_linear_t(sisic_ctx*, const float* x, int B, int K, const float* wt, const float* bias, int R,
+                    float* out, hipStream_t s);
+int launch_transpose2d(sisic_ctx*, const float* in, int rows, int cols, float* out, int out_ld, int out_col0,
+                       hipStream_t s);
+
+}  // namespace sisic

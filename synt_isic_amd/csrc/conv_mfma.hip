@@ -1,0 +1,387 @@
+// conv_mfma.hip -- fp32 NCHW convolution as an implicit GEMM on the gfx950 f32 MFMA pipe.
+//
+// Replaces every F.conv2d instance on the hot path (52 conv3x3 + 14 conv1x1 shortcuts per
+// UNet forward, plus the attention q/k/v/out projections which are 1x1 convolutions in
+// NCHW) together with the elementwise work diffusers runs around them -- GroupNorm-apply,
+// SiLU, torch.cat of the skip tensor, nearest 2x upsampling, the time-embedding add and
+// the residual add.
+//
+// GEMM view:  D[co, pixel] = sum_k W[co, k] * X[k, pixel],  k = (ci, ky, kx).
+//   * pixels ride the MFMA lane dimension, so NCHW rows are read and written as
+//     contiguous 128-byte segments and no layout change is needed at the boundary;
+//   * v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, one VGPR per operand; the two k of an
+//     instruction are two consecutive input channels at the same filter tap;
+//   * a workgroup owns CO_TILE=64 output channels x PIX pixels (a TH x TW rectangle of
+//     one image) and walks the input channels in chunks of CIC, double-buffered in LDS:
+//     the input halo tile [CIC][IH][IW] (GroupNorm+SiLU applied on the way in, zero
+//     padding after it) and the weight slab [CIC][k*k][64];
+//   * operands are read from LDS with ds_read_b32 at compile-time offsets from one
+//     per-lane base each; per k-step a wave issues MT+NT reads for MT*NT MFMAs.
+//
+// Algorithmic bytes per launch: 4*B*(Cin*Hin*Win + Cout*Hout*Wout)
+//   + 4*(Cin*Cout*k*k + Cout) (+ 4*B*Cout*Hout*Wout when a residual is read).
+#include "common.h"
+
+namespace sisic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float* in0;
+    const float* in1;
+    int c0, c1;
+    int B, Hin, Win;   // source tensors
+    int Hc, Wc;        // conv input extent (after the optional 2x upsample)
+    int Hout, Wout;
+    int ups;
+    const float* w;    // packed [Cin_pad][KK][cout_pad]
+    int cout_pad;
+    const float* bias;
+    int Cout;
+    const float* gn_scale;
+    const float* gn_shift;
+    int gn_silu;
+    const float* chan_bias;
+    int chan_bias_stride;
+    const float* residual;
+    int relu;
+    float* out;
+    int tiles_x, tiles_y, n_co_tiles, nwg, nchunks;
+};
+
+__device__ __forceinline__ float silu_f(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC>
+struct ConvGeom {
+    static constexpr int NWAVES = WM * WN;
+    static constexpr int NTHR = 64 * NWAVES;
+    static constexpr int CO_TILE = WM * MT * 32;
+    static constexpr int PIX = WN * NT * 32;
+    static constexpr int TH = PIX / TW;
+    static constexpr int KK = KS * KS;
+    static constexpr int PAD = KS / 2;
+    static constexpr int IH = (TH - 1) * STRIDE + KS;
+    static constexpr int IW = (TW - 1) * STRIDE + KS;
+    static constexpr int CHS = IH * IW;                       // LDS floats per staged channel
+    static constexpr int TPC = NTHR / CIC;                    // threads staging one channel
+    static constexpr int EPT = (CHS + TPC - 1) / TPC;         // input elements per thread per chunk
+    static constexpr int IN_BUF = ((CIC * CHS + 3) / 4) * 4;  // floats, 16-B multiple
+    static constexpr int W_BUF = CIC * KK * CO_TILE;
+    static constexpr int W_F4 = W_BUF / 4;
+    static constexpr int W_F4_PT = (W_F4 + NTHR - 1) / NTHR;
+    static constexpr size_t LDS_BYTES = size_t(2) * (IN_BUF + W_BUF) * sizeof(float);
+    static_assert(CO_TILE == CONV_CO_TILE, "weight packing assumes 64-channel tiles");
+    static_assert(PIX % TW == 0, "tile must be whole rows");
+    static_assert(NTHR % CIC == 0, "staging split");
+    static_assert(CIC % 2 == 0, "two channels per MFMA");
+};
+
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC>
+__global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvParams p) {
+    using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const in_lds = smem;                    // [2][IN_BUF]
+    float* const w_lds = smem + 2 * G::IN_BUF;     // [2][W_BUF]
+
+    // ---- which tile: XCD-aware bijective remap (blocks b, b+8 share an XCD's L2) so that the
+    // co-tiles of one pixel tile and the neighbouring pixel tiles of one image land on one XCD.
+    int work;
+    {
+        const int L = blockIdx.x, nwg = p.nwg;
+        const int xcd = L & 7, slot = L >> 3, q = nwg >> 3, r = nwg & 7;
+        work = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int co_t = work % p.n_co_tiles;
+    int tile = work / p.n_co_tiles;
+    const int tx = tile % p.tiles_x;
+    tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y;
+    const int b = tile / p.tiles_y;
+    const int oy0 = ty * G::TH, ox0 = tx * TW;   // output-space origin of the tile
+    const int co0 = co_t * G::CO_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // ---- input staging plan (invariant over the channel loop)
+    const int sci = tid / G::TPC;   // staged channel within the chunk
+    const int sl = tid % G::TPC;
+    const int HWin = p.Hin * p.Win;
+    const int Cin = p.c0 + p.c1;
+    int goff[G::EPT];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < G::EPT; ++i) {
+        const int e = sl + i * G::TPC;
+        const int yy = e / G::IW, xx = e % G::IW;
+        const int gy = oy0 * STRIDE - G::PAD + yy;
+        const int gx = ox0 * STRIDE - G::PAD + xx;
+        const bool v = (e < G::CHS) && gy >= 0 && gy < p.Hc && gx >= 0 && gx < p.Wc;
+        goff[i] = v ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : 0;
+        vmask |= (v ? 1u : 0u) << i;
+    }
+    static_assert(G::EPT <= 32, "valid mask is 32 bits");
+
+    // ---- MFMA operand bases
+    const int a_base = half * G::KK * G::CO_TILE + wm * MT * 32 + l31;
+    int b_base;
+    {
+        const int pix = wn * NT * 32 + l31;
+        const int y = pix / TW, x = pix % TW;
+        b_base = half * G::CHS + (y * STRIDE) * G::IW + x * STRIDE;
+    }
+    // offset of N-tile nt relative to nt=0 (32 pixels further along the tile)
+    constexpr int NT_STEP = (TW >= 32) ? ((TW > 32) ? 32 * STRIDE : STRIDE * G::IW) : (32 / TW) * STRIDE * G::IW;
+    static_assert(TW >= 32 || 32 % TW == 0, "TW must divide 32");
+    static_assert(TW <= 32 || TW % 32 == 0, "TW must be a multiple of 32");
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    float rin[G::EPT];
+    float4 rw[G::W_F4_PT];
+    float gsc = 1.0f, gsh = 0.0f;
+    bool cval = false;
+
+    auto load_chunk = [&](int chunk) {
+        const int c = chunk * CIC + sci;
+        cval = c < Cin;
+        const float* src = p.in0;
+        if (cval) {
+            src = (c < p.c0) ? p.in0 + ((size_t)b * p.c0 + c) * HWin
+                             : p.in1 + ((size_t)b * p.c1 + (c - p.c0)) * HWin;
+        }
+#pragma unroll
+        for (int i = 0; i < G::EPT; ++i) {
+            const bool v = cval && ((vmask >> i) & 1u);
+            rin[i] = v ? src[goff[i]] : 0.0f;
+        }
+        if (p.gn_scale != nullptr) {
+            gsc = cval ? p.gn_scale[(size_t)b * Cin + c] : 1.0f;
+            gsh = cval ? p.gn_shift[(size_t)b * Cin + c] : 0.0f;
+        }
+        const float* wsrc = p.w + (size_t)chunk * CIC * G::KK * p.cout_pad + co0;
+#pragma unroll
+        for (int i = 0; i < G::W_F4_PT; ++i) {
+            const int f = tid + i * G::NTHR;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < G::W_F4) {
+                const int rr = f / (G::CO_TILE / 4), c4 = f % (G::CO_TILE / 4);
+                v = *reinterpret_cast<const float4*>(wsrc + (size_t)rr * p.cout_pad + c4 * 4);
+            }
+            rw[i] = v;
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+        float* dst = in_lds + buf * G::IN_BUF + sci * G::CHS + sl;
+        const bool gn = p.gn_scale != nullptr;
+        const bool act = p.gn_silu != 0;
+#pragma unroll
+        for (int i = 0; i < G::EPT; ++i) {
+            const int e = sl + i * G::TPC;
+            if (e < G::CHS) {
+                float v = rin[i];
+                if (gn) {
+                    v = v * gsc + gsh;
+                    if (act) v = silu_f(v);
+                    if (!(cval && ((vmask >> i) & 1u))) v = 0.0f;   // padding stays zero after the prologue
+                }
+                dst[i * G::TPC] = v;
+            }
+        }
+        float* wdst = w_lds + buf * G::W_BUF;
+#pragma unroll
+        for (int i = 0; i < G::W_F4_PT; ++i) {
+            const int f = tid + i * G::NTHR;
+            if (f < G::W_F4) *reinterpret_cast<float4*>(wdst + f * 4) = rw[i];
+        }
+    };
+
+    auto compute_chunk = [&](int buf) {
+        const float* A = w_lds + buf * G::W_BUF + a_base;
+        const float* Bm = in_lds + buf * G::IN_BUF + b_base;
+#pragma unroll
+        for (int cp = 0; cp < CIC / 2; ++cp) {
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    float a[MT], bb[NT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        a[m] = A[(2 * cp * G::KK + ky * KS + kx) * G::CO_TILE + m * 32];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        bb[n] = Bm[2 * cp * G::CHS + ky * G::IW + kx + n * NT_STEP];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- channel loop: register-staged double buffering, one barrier per chunk
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        const bool more = chunk + 1 < p.nchunks;
+        if (more) load_chunk(chunk + 1);
+        compute_chunk(buf);
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + per-sample channel bias (time embedding) + residual, NCHW store
+    const size_t HWout = (size_t)p.Hout * p.Wout;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int pix = wn * NT * 32 + n * 32 + l31;
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+        const bool pv = oy < p.Hout && ox < p.Wout;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pv && co < p.Cout) {
+                    const size_t idx = ((size_t)b * p.Cout + co) * HWout + (size_t)oy * p.Wout + ox;
+                    float v = acc[m][n][r];
+                    if (p.bias) v += p.bias[co];
+                    if (p.chan_bias) v += p.chan_bias[(size_t)b * p.chan_bias_stride + co];
+                    if (p.residual) v += p.residual[idx];
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    p.out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// OIHW -> [Cin_pad][KK][cout_pad], zero padded
+__global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, int cin_pad, int cout_pad,
+                                 float* __restrict__ out) {
+    const size_t total = (size_t)cin_pad * KK * cout_pad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_pad);
+        const size_t r = i / cout_pad;
+        const int tap = (int)(r % KK);
+        const int ci = (int)(r / KK);
+        float v = 0.0f;
+        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KK + tap];
+        out[i] = v;
+    }
+}
+
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC>
+static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
+    using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
+    p.tiles_x = cdiv(p.Wout, TW);
+    p.tiles_y = cdiv(p.Hout, G::TH);
+    p.n_co_tiles = p.cout_pad / G::CO_TILE;
+    p.nchunks = cdiv(p.c0 + p.c1, CIC);
+    const int64_t nwg = (int64_t)p.B * p.tiles_x * p.tiles_y * p.n_co_tiles;
+    SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d: grid of %lld workgroups unsupported", (long long)nwg);
+    p.nwg = (int)nwg;
+    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)G::LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(G::NTHR), G::LDS_BYTES, s, p);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float* packed, hipStream_t s) {
+    SISIC_REQUIRE(k == 1 || k == 3, "conv_pack: ksize %d unsupported", k);
+    const int cin_pad = conv_cin_pad(Cin, k), cout_pad = conv_cout_pad(Cout);
+    const size_t total = (size_t)cin_pad * k * k * cout_pad;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, k * k, cin_pad, cout_pad, packed);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// Tile configurations.  id -> (KS, STRIDE, MT, NT, WM, WN, TW):
+//   3x3 s1:  1: 2,2,1,4,TW64   2: 2,2,1,4,TW32   3: 2,2,1,4,TW16   4: 1,1,2,2,TW8   5: 2,1,1,4,TW16 (PIX128)
+//   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
+//   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
+int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
+    SISIC_REQUIRE(a.in0 && a.w_packed && a.out, "conv2d: null tensor");
+    SISIC_REQUIRE(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.c0 > 0 && a.c1 >= 0 && a.Cout > 0, "conv2d: bad shape");
+    SISIC_REQUIRE((a.c1 == 0) == (a.in1 == nullptr), "conv2d: in1/c1 mismatch");
+    SISIC_REQUIRE(a.ksize == 1 || a.ksize == 3, "conv2d: ksize %d unsupported", a.ksize);
+    SISIC_REQUIRE(a.stride == 1 || (a.stride == 2 && a.ksize == 3), "conv2d: stride %d unsupported", a.stride);
+    SISIC_REQUIRE(!(a.upsample && a.stride != 1), "conv2d: upsample with stride");
+    SISIC_REQUIRE((a.gn_scale == nullptr) == (a.gn_shift == nullptr), "conv2d: gn_scale/gn_shift mismatch");
+
+    ConvParams p{};
+    p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1;
+    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win;
+    p.ups = a.upsample ? 1 : 0;
+    p.Hc = a.Hin << p.ups; p.Wc = a.Win << p.ups;
+    const int pad = a.ksize / 2;
+    p.Hout = (p.Hc + 2 * pad - a.ksize) / a.stride + 1;
+    p.Wout = (p.Wc + 2 * pad - a.ksize) / a.stride + 1;
+    p.w = a.w_packed; p.cout_pad = conv_cout_pad(a.Cout);
+    p.bias = a.bias; p.Cout = a.Cout;
+    p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
+    p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu; p.out = a.out;
+
+    const int Cin = a.c0 + a.c1;
+    const double kk = double(a.ksize) * a.ksize;
+    const double out_elems = double(a.B) * a.Cout * p.Hout * p.Wout;
+    const double bytes = 4.0 * (double(a.B) * Cin * a.Hin * a.Win + out_elems) + 4.0 * (Cin * a.Cout * kk + a.Cout) +
+                         (a.residual ? 4.0 * out_elems : 0.0);
+    const double flops = 2.0 * out_elems * Cin * kk;
+    ProfileScope prof(ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops);
+
+    int cfg = a.tile_cfg;
+    if (a.ksize == 1) {
+        // 1x1: the image is a flat row of H*W pixels
+        p.Hin = 1; p.Win = a.Hin * a.Win; p.Hc = 1; p.Wc = p.Win; p.Hout = 1; p.Wout = p.Win; p.ups = 0;
+        SISIC_REQUIRE(!a.upsample, "conv2d: 1x1 with upsample");
+        if (cfg == 0) cfg = (p.Wout <= 64) ? 22 : 21;
+        switch (cfg) {
+            case 21: return launch_cfg<1, 1, 2, 2, 1, 4, 256, 16>(ctx, p, s);
+            case 22: return launch_cfg<1, 1, 1, 1, 2, 2, 64, 16>(ctx, p, s);
+            case 23: return launch_cfg<1, 1, 2, 1, 1, 4, 128, 16>(ctx, p, s);
+        }
+    } else if (a.stride == 1) {
+        if (cfg == 0) cfg = p.Wout >= 48 ? 1 : (p.Wout >= 24 ? 2 : (p.Wout >= 12 ? 3 : 4));
+        switch (cfg) {
+            case 1: return launch_cfg<3, 1, 2, 2, 1, 4, 64, 8>(ctx, p, s);
+            case 2: return launch_cfg<3, 1, 2, 2, 1, 4, 32, 8>(ctx, p, s);
+            case 3: return launch_cfg<3, 1, 2, 2, 1, 4, 16, 8>(ctx, p, s);
+            case 4: return launch_cfg<3, 1, 1, 1, 2, 2, 8, 8>(ctx, p, s);
+            case 5: return launch_cfg<3, 1, 2, 1, 1, 4, 16, 8>(ctx, p, s);
+        }
+    } else {
+        if (cfg == 0) cfg = p.Wout >= 24 ? 11 : (p.Wout >= 12 ? 12 : 13);
+        switch (cfg) {
+            case 11: return launch_cfg<3, 2, 2, 1, 1, 4, 32, 8>(ctx, p, s);
+            case 12: return launch_cfg<3, 2, 2, 1, 1, 4, 16, 8>(ctx, p, s);
+            case 13: return launch_cfg<3, 2, 1, 1, 2, 2, 8, 8>(ctx, p, s);
+        }
+    }
+    set_error("conv2d: tile_cfg %d invalid for ksize %d stride %d", cfg, a.ksize, a.stride);
+    return SISIC_EINVAL;
+}
+
+}  // namespace sisic

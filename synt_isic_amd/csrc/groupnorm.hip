@@ -1,0 +1,112 @@
+// groupnorm.hip -- GroupNorm statistics, folded with the affine parameters.
+//
+// Replaces the reduction half of torch.nn.GroupNorm(32, C, eps=1e-5) in ResnetBlock2D
+// (norm1/norm2), Attention.group_norm and conv_norm_out.
+// The normalise+affine(+SiLU) half is fused into the consuming convolution's load path
+// (conv_mfma.hip), so the activation tensor is read once here and once by the conv.
+//
+// One workgroup per (sample, group): two passes over the group's cpg*HW elements
+// (mean, then centred sum of squares -- the second pass hits L2), wavefront-shuffle
+// reductions, then   scale[b,c] = gamma[c]*rstd,  shift[b,c] = beta[c] - mean*scale[b,c].
+// The input may be the channel concatenation of two tensors (up-path skip connections);
+// a group may straddle the seam.
+//
+// HBM-bound.  Algorithmic bytes per launch: 4*B*C*HW (read once) + 8*B*C (written).
+#include "common.h"
+
+namespace sisic {
+
+constexpr int GN_THREADS = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();   // protect red[] from the previous use
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < GN_THREADS / 64; ++w) t += red[w];
+    return t;
+}
+
+__global__ void __launch_bounds__(GN_THREADS)
+gn_stats_kernel(const float* __restrict__ in0, int c0, const float* __restrict__ in1, int c1, int HW, int groups,
+                float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                float* __restrict__ scale, float* __restrict__ shift, int aligned16) {
+    __shared__ float red[GN_THREADS / 64];
+    const int C = c0 + c1;
+    const int cpg = C / groups;
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int tid = threadIdx.x;
+    const bool vec = aligned16 && (HW & 3) == 0;
+
+    auto plane = [&](int c) -> const float* {
+        return (c < c0) ? in0 + ((size_t)b * c0 + c) * HW : in1 + ((size_t)b * c1 + (c - c0)) * HW;
+    };
+
+    float s = 0.0f;
+    for (int j = 0; j < cpg; ++j) {
+        const float* src = plane(g * cpg + j);
+        if (vec) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            for (int i = tid; i < HW / 4; i += GN_THREADS) {
+                const float4 v = s4[i];
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (int i = tid; i < HW; i += GN_THREADS) s += src[i];
+        }
+    }
+    const float n = (float)cpg * (float)HW;
+    const float mean = block_sum(s, red) / n;
+
+    float q = 0.0f;
+    for (int j = 0; j < cpg; ++j) {
+        const float* src = plane(g * cpg + j);
+        if (vec) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            for (int i = tid; i < HW / 4; i += GN_THREADS) {
+                const float4 v = s4[i];
+                const float a = v.x - mean, bq = v.y - mean, c = v.z - mean, d = v.w - mean;
+                q += (a * a + bq * bq) + (c * c + d * d);
+            }
+        } else {
+            for (int i = tid; i < HW; i += GN_THREADS) {
+                const float a = src[i] - mean;
+                q += a * a;
+            }
+        }
+    }
+    const float var = block_sum(q, red) / n;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (tid < cpg) {
+        const int c = g * cpg + tid;
+        const float sc = gamma[c] * rstd;
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = beta[c] - mean * sc;
+    }
+}
+
+int launch_gn_stats(sisic_ctx* ctx, const float* in0, int c0, const float* in1, int c1, int B, int HW, int groups,
+                    float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s) {
+    SISIC_REQUIRE(in0 && gamma && beta && scale && shift, "groupnorm_stats: null tensor");
+    SISIC_REQUIRE((c1 == 0) == (in1 == nullptr), "groupnorm_stats: in1/c1 mismatch");
+    const int C = c0 + c1;
+    SISIC_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0, "groupnorm_stats: C=%d not divisible by groups=%d", C, groups);
+    SISIC_REQUIRE(C / groups <= GN_THREADS, "groupnorm_stats: %d channels per group unsupported", C / groups);
+    ProfileScope prof(ctx, s, PK_GN, 4.0 * B * C * HW + 8.0 * B * C, 0.0);
+    const int aligned16 = ((reinterpret_cast<uintptr_t>(in0) | reinterpret_cast<uintptr_t>(in1)) & 15) == 0;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(GN_THREADS), 0, s, in0, c0, in1, c1, HW, groups, eps,
+                       gamma, beta, scale, shift, aligned16);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+}  // namespace sisic

@@ -1,0 +1,713 @@
+// unet.cpp -- the UNet2DModel executor and the reverse-diffusion loop.
+//
+// Walks the architecture the reference configures at core/generator/model_manager.py:173-194
+//  and issues the fused HIP kernels:
+//     ResnetBlock2D  = gn_stats -> conv3x3[GN+SiLU prologue, +bias +time-embedding]
+//                      -> gn_stats -> conv3x3[GN+SiLU prologue, +bias +shortcut/residual]
+//                      (conv1x1 shortcut on the raw, possibly concatenated input when Cin != Cout)
+//     Attention      = gn_stats -> conv1x1[GN prologue] (q,k,v in one launch) -> attention core
+//                      -> conv1x1[+bias +residual]
+//     Downsample2D   = conv3x3 stride 2;   Upsample2D = conv3x3 reading through a nearest-2x map
+// torch.cat of the skip connections never materialises: consumers read two source tensors.
+// sisic_sample() runs the loop of core/generator/image_generator.py:395-403 without returning
+// to the host between steps.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "common.h"
+
+using namespace sisic;
+
+namespace {
+
+struct ConvW {            // one convolution's parameters
+    int cout = 0, cin = 0, k = 0;
+    int w_idx = -1, b_idx = -1;   // indices into the state-dict tensor table (raw)
+    float* packed = nullptr;      // device, packed layout
+    const float* bias = nullptr;  // device
+};
+
+struct NormW {
+    int c = 0;
+    int w_idx = -1, b_idx = -1;
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+};
+
+struct ResnetW {
+    int cin = 0, cout = 0;
+    NormW norm1, norm2;
+    ConvW conv1, conv2, shortcut;   // shortcut.k == 0 when absent
+    int temb_w_idx = -1, temb_b_idx = -1;
+    int temb_off = 0;               // column offset in the fused time-embedding projection
+};
+
+struct AttnW {
+    int c = 0;
+    NormW norm;
+    int q_w = -1, q_b = -1, k_w = -1, k_b = -1, v_w = -1, v_b = -1, o_w = -1, o_b = -1;
+    float* qkv_packed = nullptr;    // [3C <- C] 1x1 conv
+    float* qkv_bias = nullptr;      // [3C]
+    ConvW out;                      // to_out.0 as 1x1 conv
+};
+
+struct Buf {
+    float* p = nullptr;
+    int C = 0, H = 0, W = 0;
+    int refs = 0;
+};
+
+struct PoolBlock {
+    float* p;
+    size_t bytes;
+    bool free_;
+};
+
+}  // namespace
+
+struct sisic_unet {
+    sisic_ctx* ctx = nullptr;
+    sisic_unet_config cfg{};
+    std::vector<float> freqs;
+
+    // expected state dict
+    std::vector<std::string> names;
+    std::vector<int64_t> numels;
+    std::vector<size_t> offsets;       // float offset of each raw tensor in `raw`
+    std::map<std::string, int> index;
+    float* raw = nullptr;              // device arena with the raw tensors
+    size_t raw_floats = 0;
+    std::vector<float*> owned;         // derived device buffers (packed weights, ...)
+    bool loaded = false;
+
+    // architecture
+    ConvW conv_in, conv_out;
+    NormW norm_out;
+    int temb_w1 = -1, temb_b1 = -1, temb_w2 = -1, temb_b2 = -1;
+    float* d_freqs = nullptr;
+    float* w1t = nullptr;  // [2*n_freqs][hidden]
+    float* w2t = nullptr;  // [hidden][hidden]
+    float* tproj_wt = nullptr;   // [hidden][tproj_R]
+    float* tproj_b = nullptr;    // [tproj_R]
+    int hidden = 0, tproj_R = 0;
+    std::vector<std::vector<ResnetW>> down_res, up_res;
+    std::vector<std::vector<AttnW>> down_attn, up_attn;
+    std::vector<ConvW> downsamplers, upsamplers;   // k==0 when absent
+    ResnetW mid_res[2];
+    AttnW mid_attn;
+    int max_c = 0;
+
+    // workspace
+    std::vector<PoolBlock> pool;
+    int ws_B = 0, ws_H = 0, ws_W = 0;
+    float* t_vals = nullptr;     // [B] or [T]
+    float* temb_act = nullptr;   // [B or T, hidden]
+    float* tproj = nullptr;      // [B or T, tproj_R]
+    float* gn_scale = nullptr;   // [B, max_c]
+    float* gn_shift = nullptr;
+    size_t t_vals_cap = 0, temb_act_cap = 0, tproj_cap = 0, gn_scale_cap = 0, gn_shift_cap = 0;
+    static constexpr int STAGE_SLOTS = 4;
+    float* stage_host = nullptr; // pinned upload ring
+    size_t stage_cap = 0;
+    uint64_t stage_next = 0;
+    hipEvent_t stage_ev[STAGE_SLOTS] = {};
+    bool stage_used[STAGE_SLOTS] = {};
+    float* eps_buf = nullptr;    // sampling loop scratch [B,C,H,W]
+    size_t eps_floats = 0;
+
+    int add(const std::string& name, int64_t numel) {
+        index[name] = (int)names.size();
+        names.push_back(name);
+        numels.push_back(numel);
+        return (int)names.size() - 1;
+    }
+    const float* rawp(int idx) const { return raw + offsets[idx]; }
+};
+
+namespace {
+
+// ------------------------------------------------------------------ architecture description
+void add_conv(sisic_unet* u, ConvW& c, const std::string& name, int cout, int cin, int k) {
+    c.cout = cout; c.cin = cin; c.k = k;
+    c.w_idx = u->add(name + ".weight", (int64_t)cout * cin * k * k);
+    c.b_idx = u->add(name + ".bias", cout);
+}
+void add_norm(sisic_unet* u, NormW& n, const std::string& name, int c) {
+    n.c = c;
+    n.w_idx = u->add(name + ".weight", c);
+    n.b_idx = u->add(name + ".bias", c);
+}
+void add_resnet(sisic_unet* u, ResnetW& r, const std::string& name, int cin, int cout) {
+    r.cin = cin; r.cout = cout;
+    add_norm(u, r.norm1, name + ".norm1", cin);
+    add_conv(u, r.conv1, name + ".conv1", cout, cin, 3);
+    r.temb_w_idx = u->add(name + ".time_emb_proj.weight", (int64_t)cout * u->hidden);
+    r.temb_b_idx = u->add(name + ".time_emb_proj.bias", cout);
+    r.temb_off = u->tproj_R;
+    u->tproj_R += cout;
+    add_norm(u, r.norm2, name + ".norm2", cout);
+    add_conv(u, r.conv2, name + ".conv2", cout, cout, 3);
+    if (cin != cout) add_conv(u, r.shortcut, name + ".conv_shortcut", cout, cin, 1);
+    u->max_c = std::max(u->max_c, std::max(cin, cout));
+}
+void add_attn(sisic_unet* u, AttnW& a, const std::string& name, int c) {
+    a.c = c;
+    add_norm(u, a.norm, name + ".group_norm", c);
+    a.q_w = u->add(name + ".to_q.weight", (int64_t)c * c); a.q_b = u->add(name + ".to_q.bias", c);
+    a.k_w = u->add(name + ".to_k.weight", (int64_t)c * c); a.k_b = u->add(name + ".to_k.bias", c);
+    a.v_w = u->add(name + ".to_v.weight", (int64_t)c * c); a.v_b = u->add(name + ".to_v.bias", c);
+    add_conv(u, a.out, name + ".to_out.0", c, c, 1);
+    u->max_c = std::max(u->max_c, c);
+}
+
+int describe(sisic_unet* u) {
+    const sisic_unet_config& cfg = u->cfg;
+    const int n = cfg.n_blocks;
+    const int* boc = cfg.block_out_channels;
+    u->hidden = 4 * boc[0];
+    add_conv(u, u->conv_in, "conv_in", boc[0], cfg.in_channels, 3);
+    u->temb_w1 = u->add("time_embedding.linear_1.weight", (int64_t)u->hidden * boc[0]);
+    u->temb_b1 = u->add("time_embedding.linear_1.bias", u->hidden);
+    u->temb_w2 = u->add("time_embedding.linear_2.weight", (int64_t)u->hidden * u->hidden);
+    u->temb_b2 = u->add("time_embedding.linear_2.bias", u->hidden);
+
+    u->down_res.resize(n); u->down_attn.resize(n); u->downsamplers.resize(n);
+    int out_ch = boc[0];
+    for (int i = 0; i < n; ++i) {
+        const int in_ch = out_ch;
+        out_ch = boc[i];
+        u->down_res[i].resize(cfg.layers_per_block);
+        if (cfg.down_attn[i]) u->down_attn[i].resize(cfg.layers_per_block);
+        for (int j = 0; j < cfg.layers_per_block; ++j) {
+            const std::string base = "down_blocks." + std::to_string(i);
+            add_resnet(u, u->down_res[i][j], base + ".resnets." + std::to_string(j), j == 0 ? in_ch : out_ch, out_ch);
+            if (cfg.down_attn[i]) add_attn(u, u->down_attn[i][j], base + ".attentions." + std::to_string(j), out_ch);
+        }
+        if (i != n - 1)
+            add_conv(u, u->downsamplers[i], "down_blocks." + std::to_string(i) + ".downsamplers.0.conv", out_ch, out_ch, 3);
+    }
+    const int mid = boc[n - 1];
+    add_resnet(u, u->mid_res[0], "mid_block.resnets.0", mid, mid);
+    add_attn(u, u->mid_attn, "mid_block.attentions.0", mid);
+    add_resnet(u, u->mid_res[1], "mid_block.resnets.1", mid, mid);
+
+    u->up_res.resize(n); u->up_attn.resize(n); u->upsamplers.resize(n);
+    out_ch = boc[n - 1];
+    for (int i = 0; i < n; ++i) {
+        const int prev_out = out_ch;
+        out_ch = boc[n - 1 - i];
+        const int in_ch = boc[n - 1 - std::min(i + 1, n - 1)];
+        const int layers = cfg.layers_per_block + 1;
+        u->up_res[i].resize(layers);
+        if (cfg.up_attn[i]) u->up_attn[i].resize(layers);
+        for (int j = 0; j < layers; ++j) {
+            const int skip_ch = (j == layers - 1) ? in_ch : out_ch;
+            const int res_in = (j == 0) ? prev_out : out_ch;
+            const std::string base = "up_blocks." + std::to_string(i);
+            add_resnet(u, u->up_res[i][j], base + ".resnets." + std::to_string(j), res_in + skip_ch, out_ch);
+            if (cfg.up_attn[i]) add_attn(u, u->up_attn[i][j], base + ".attentions." + std::to_string(j), out_ch);
+        }
+        if (i != n - 1)
+            add_conv(u, u->upsamplers[i], "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", out_ch, out_ch, 3);
+    }
+    add_norm(u, u->norm_out, "conv_norm_out", boc[0]);
+    add_conv(u, u->conv_out, "conv_out", cfg.out_channels, boc[0], 3);
+
+    u->offsets.resize(u->names.size());
+    size_t off = 0;
+    for (size_t i = 0; i < u->names.size(); ++i) {
+        u->offsets[i] = off;
+        off += ((size_t)u->numels[i] + 3) / 4 * 4;   // keep every tensor 16-byte aligned
+    }
+    u->raw_floats = off;
+    return SISIC_OK;
+}
+
+// ------------------------------------------------------------------ derived weights
+int dev_alloc(sisic_unet* u, size_t floats, float** out) {
+    void* p = nullptr;
+    SISIC_HIP(hipMalloc(&p, std::max<size_t>(floats, 4) * sizeof(float)));
+    u->owned.push_back(static_cast<float*>(p));
+    *out = static_cast<float*>(p);
+    return SISIC_OK;
+}
+
+int prepare_conv(sisic_unet* u, ConvW& c) {
+    if (c.k == 0) return SISIC_OK;
+    SISIC_TRY(dev_alloc(u, (size_t)sisic_conv_packed_numel(c.cout, c.cin, c.k), &c.packed));
+    SISIC_TRY(launch_conv_pack(u->ctx, u->rawp(c.w_idx), c.cout, c.cin, c.k, c.packed, nullptr));
+    c.bias = u->rawp(c.b_idx);
+    return SISIC_OK;
+}
+void prepare_norm(sisic_unet* u, NormW& n) {
+    n.gamma = u->rawp(n.w_idx);
+    n.beta = u->rawp(n.b_idx);
+}
+int prepare_resnet(sisic_unet* u, ResnetW& r) {
+    prepare_norm(u, r.norm1);
+    prepare_norm(u, r.norm2);
+    SISIC_TRY(prepare_conv(u, r.conv1));
+    SISIC_TRY(prepare_conv(u, r.conv2));
+    SISIC_TRY(prepare_conv(u, r.shortcut));
+    // time_emb_proj.weight [cout, hidden] -> columns [temb_off, temb_off+cout) of tproj_wt [hidden][R]
+    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(r.temb_w_idx), r.cout, u->hidden, u->tproj_wt, u->tproj_R, r.temb_off, nullptr));
+    SISIC_HIP(hipMemcpy(u->tproj_b + r.temb_off, u->rawp(r.temb_b_idx), (size_t)r.cout * sizeof(float), hipMemcpyDeviceToDevice));
+    return SISIC_OK;
+}
+int prepare_attn(sisic_unet* u, AttnW& a) {
+    prepare_norm(u, a.norm);
+    const int c = a.c;
+    // q,k,v as one [3C, C] 1x1 convolution
+    float* cat = nullptr;
+    SISIC_TRY(dev_alloc(u, (size_t)3 * c * c, &cat));
+    const size_t wbytes = (size_t)c * c * sizeof(float);
+    SISIC_HIP(hipMemcpy(cat, u->rawp(a.q_w), wbytes, hipMemcpyDeviceToDevice));
+    SISIC_HIP(hipMemcpy(cat + (size_t)c * c, u->rawp(a.k_w), wbytes, hipMemcpyDeviceToDevice));
+    SISIC_HIP(hipMemcpy(cat + (size_t)2 * c * c, u->rawp(a.v_w), wbytes, hipMemcpyDeviceToDevice));
+    SISIC_TRY(dev_alloc(u, (size_t)sisic_conv_packed_numel(3 * c, c, 1), &a.qkv_packed));
+    SISIC_TRY(launch_conv_pack(u->ctx, cat, 3 * c, c, 1, a.qkv_packed, nullptr));
+    SISIC_TRY(dev_alloc(u, (size_t)3 * c, &a.qkv_bias));
+    SISIC_HIP(hipMemcpy(a.qkv_bias, u->rawp(a.q_b), c * sizeof(float), hipMemcpyDeviceToDevice));
+    SISIC_HIP(hipMemcpy(a.qkv_bias + c, u->rawp(a.k_b), c * sizeof(float), hipMemcpyDeviceToDevice));
+    SISIC_HIP(hipMemcpy(a.qkv_bias + 2 * c, u->rawp(a.v_b), c * sizeof(float), hipMemcpyDeviceToDevice));
+    SISIC_TRY(prepare_conv(u, a.out));
+    return SISIC_OK;
+}
+
+int prepare_all(sisic_unet* u) {
+    const int nin = 2 * u->cfg.n_freqs;
+    SISIC_TRY(dev_alloc(u, u->cfg.n_freqs, &u->d_freqs));
+    SISIC_HIP(hipMemcpy(u->d_freqs, u->freqs.data(), u->freqs.size() * sizeof(float), hipMemcpyHostToDevice));
+    SISIC_TRY(dev_alloc(u, (size_t)nin * u->hidden, &u->w1t));
+    SISIC_TRY(dev_alloc(u, (size_t)u->hidden * u->hidden, &u->w2t));
+    SISIC_TRY(dev_alloc(u, (size_t)u->hidden * u->tproj_R, &u->tproj_wt));
+    SISIC_TRY(dev_alloc(u, (size_t)u->tproj_R, &u->tproj_b));
+    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(u->temb_w1), u->hidden, nin, u->w1t, u->hidden, 0, nullptr));
+    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(u->temb_w2), u->hidden, u->hidden, u->w2t, u->hidden, 0, nullptr));
+    SISIC_TRY(prepare_conv(u, u->conv_in));
+    SISIC_TRY(prepare_conv(u, u->conv_out));
+    prepare_norm(u, u->norm_out);
+    for (auto& blk : u->down_res) for (auto& r : blk) SISIC_TRY(prepare_resnet(u, r));
+    for (auto& blk : u->up_res) for (auto& r : blk) SISIC_TRY(prepare_resnet(u, r));
+    for (auto& r : u->mid_res) SISIC_TRY(prepare_resnet(u, r));
+    for (auto& blk : u->down_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a));
+    for (auto& blk : u->up_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a));
+    SISIC_TRY(prepare_attn(u, u->mid_attn));
+    for (auto& c : u->downsamplers) SISIC_TRY(prepare_conv(u, c));
+    for (auto& c : u->upsamplers) SISIC_TRY(prepare_conv(u, c));
+    SISIC_HIP(hipDeviceSynchronize());
+    return SISIC_OK;
+}
+
+// ------------------------------------------------------------------ workspace
+void pool_release_all(sisic_unet* u) {
+    for (auto& b : u->pool) (void)hipFree(b.p);
+    u->pool.clear();
+}
+
+int pool_get(sisic_unet* u, size_t floats, float** out) {
+    const size_t bytes = floats * sizeof(float);
+    for (auto& b : u->pool) {
+        if (b.free_ && b.bytes == bytes) {
+            b.free_ = false;
+            *out = b.p;
+            return SISIC_OK;
+        }
+    }
+    void* p = nullptr;
+    SISIC_HIP(hipMalloc(&p, bytes));
+    u->pool.push_back({static_cast<float*>(p), bytes, false});
+    *out = static_cast<float*>(p);
+    return SISIC_OK;
+}
+
+void pool_put(sisic_unet* u, float* p) {
+    for (auto& b : u->pool)
+        if (b.p == p) { b.free_ = true; return; }
+}
+
+int grow(float** p, size_t* have, size_t want) {
+    if (*have >= want) return SISIC_OK;
+    if (*p) SISIC_HIP(hipFree(*p));   // hipFree waits for the device, nothing can still read the old block
+    *p = nullptr; *have = 0;
+    void* q = nullptr;
+    SISIC_HIP(hipMalloc(&q, want * sizeof(float)));
+    *p = static_cast<float*>(q);
+    *have = want;
+    return SISIC_OK;
+}
+
+int ensure_rows(sisic_unet* u, size_t t_rows, size_t gn_rows) {
+    SISIC_TRY(grow(&u->t_vals, &u->t_vals_cap, t_rows));
+    SISIC_TRY(grow(&u->temb_act, &u->temb_act_cap, t_rows * u->hidden));
+    SISIC_TRY(grow(&u->tproj, &u->tproj_cap, t_rows * u->tproj_R));
+    SISIC_TRY(grow(&u->gn_scale, &u->gn_scale_cap, gn_rows * u->max_c));
+    SISIC_TRY(grow(&u->gn_shift, &u->gn_shift_cap, gn_rows * u->max_c));
+    return SISIC_OK;
+}
+
+// Host -> device upload of a few floats, ordered on the caller's stream.  The source is copied into
+// one of a small ring of pinned slots; a slot is reused only after the copy that read it has finished.
+int stage_upload(sisic_unet* u, const float* src, size_t n, float* dst, hipStream_t s) {
+    if (u->stage_cap < n) {
+        SISIC_HIP(hipDeviceSynchronize());
+        if (u->stage_host) SISIC_HIP(hipHostFree(u->stage_host));
+        u->stage_host = nullptr;
+        const size_t cap = std::max<size_t>(n, 1024);
+        void* p = nullptr;
+        SISIC_HIP(hipHostMalloc(&p, cap * sisic_unet::STAGE_SLOTS * sizeof(float), hipHostMallocDefault));
+        u->stage_host = static_cast<float*>(p);
+        u->stage_cap = cap;
+        for (int i = 0; i < sisic_unet::STAGE_SLOTS; ++i) u->stage_used[i] = false;
+    }
+    const int slot = (int)(u->stage_next++ % sisic_unet::STAGE_SLOTS);
+    if (!u->stage_ev[slot]) SISIC_HIP(hipEventCreateWithFlags(&u->stage_ev[slot], hipEventDisableTiming));
+    if (u->stage_used[slot]) SISIC_HIP(hipEventSynchronize(u->stage_ev[slot]));
+    float* h = u->stage_host + (size_t)slot * u->stage_cap;
+    std::memcpy(h, src, n * sizeof(float));
+    SISIC_HIP(hipMemcpyAsync(dst, h, n * sizeof(float), hipMemcpyHostToDevice, s));
+    SISIC_HIP(hipEventRecord(u->stage_ev[slot], s));
+    u->stage_used[slot] = true;
+    return SISIC_OK;
+}
+
+// ------------------------------------------------------------------ forward
+struct Fwd {
+    sisic_unet* u;
+    hipStream_t s;
+    int B;
+    const float* tproj;   // [B or 1, tproj_R]
+    int tproj_stride;     // tproj_R, or 0 when one row serves every sample
+    std::vector<std::unique_ptr<Buf>> bufs;
+
+    Buf* make(int C, int H, int W, int* rc) {
+        auto b = std::make_unique<Buf>();
+        b->C = C; b->H = H; b->W = W; b->refs = 1;
+        *rc = pool_get(u, (size_t)B * C * H * W, &b->p);
+        bufs.push_back(std::move(b));
+        return bufs.back().get();
+    }
+    void release(Buf* b) {
+        if (b && --b->refs == 0 && b->p) { pool_put(u, b->p); b->p = nullptr; }
+    }
+
+    int gn(const Buf* x, const Buf* skip, const NormW& n) {
+        return launch_gn_stats(u->ctx, x->p, x->C, skip ? skip->p : nullptr, skip ? skip->C : 0, B, x->H * x->W,
+                               u->cfg.norm_groups, u->cfg.norm_eps, n.gamma, n.beta, u->gn_scale, u->gn_shift, s);
+    }
+
+    int conv(const ConvW& c, const float* in0, int c0, const float* in1, int c1, int H, int W, int stride, int ups,
+             bool gn_prologue, bool silu, const float* chan_bias, const float* residual, float* out) {
+        sisic_conv_args a{};
+        a.in0 = in0; a.c0 = c0; a.in1 = in1; a.c1 = c1;
+        a.B = B; a.Hin = H; a.Win = W; a.upsample = ups; a.ksize = c.k; a.stride = stride;
+        a.w_packed = c.packed; a.bias = c.bias; a.Cout = c.cout;
+        if (gn_prologue) { a.gn_scale = u->gn_scale; a.gn_shift = u->gn_shift; a.gn_silu = silu ? 1 : 0; }
+        a.chan_bias = chan_bias; a.chan_bias_stride = tproj_stride;
+        a.residual = residual; a.out = out;
+        return launch_conv2d(u->ctx, a, s);
+    }
+
+    // out = ResnetBlock2D(cat(x, skip)); consumes nothing (caller releases inputs)
+    int resnet(const ResnetW& r, const Buf* x, const Buf* skip, Buf** out) {
+        int rc = SISIC_OK;
+        const int H = x->H, W = x->W;
+        const int c1 = skip ? skip->C : 0;
+        SISIC_REQUIRE(x->C + c1 == r.cin, "unet: resnet expects %d input channels, got %d", r.cin, x->C + c1);
+        SISIC_TRY(gn(x, skip, r.norm1));
+        Buf* h = make(r.cout, H, W, &rc); SISIC_TRY(rc);
+        SISIC_TRY(conv(r.conv1, x->p, x->C, skip ? skip->p : nullptr, c1, H, W, 1, 0, true, true,
+                       tproj + r.temb_off, nullptr, h->p));
+        const float* residual = x->p;
+        Buf* sc = nullptr;
+        if (r.shortcut.k) {
+            sc = make(r.cout, H, W, &rc); SISIC_TRY(rc);
+            SISIC_TRY(conv(r.shortcut, x->p, x->C, skip ? skip->p : nullptr, c1, H, W, 1, 0, false, false, nullptr,
+                           nullptr, sc->p));
+            residual = sc->p;
+        } else {
+            SISIC_REQUIRE(c1 == 0 && x->C == r.cout, "unet: identity shortcut with mismatched channels");
+        }
+        SISIC_TRY(gn(h, nullptr, r.norm2));
+        Buf* o = make(r.cout, H, W, &rc); SISIC_TRY(rc);
+        SISIC_TRY(conv(r.conv2, h->p, r.cout, nullptr, 0, H, W, 1, 0, true, true, nullptr, residual, o->p));
+        release(h);
+        release(sc);
+        *out = o;
+        return SISIC_OK;
+    }
+
+    int attention(const AttnW& a, const Buf* x, Buf** out) {
+        int rc = SISIC_OK;
+        const int H = x->H, W = x->W, N = H * W, C = a.c;
+        SISIC_REQUIRE(x->C == C, "unet: attention channel mismatch");
+        SISIC_TRY(gn(x, nullptr, a.norm));
+        Buf* qkv = make(3 * C, H, W, &rc); SISIC_TRY(rc);
+        ConvW cq; cq.cout = 3 * C; cq.cin = C; cq.k = 1; cq.packed = a.qkv_packed; cq.bias = a.qkv_bias;
+        SISIC_TRY(conv(cq, x->p, C, nullptr, 0, H, W, 1, 0, true, false, nullptr, nullptr, qkv->p));
+        Buf* o = make(C, H, W, &rc); SISIC_TRY(rc);
+        SISIC_TRY(launch_attention(u->ctx, qkv->p, o->p, B, C, N, u->cfg.head_dim, s));
+        release(qkv);
+        Buf* y = make(C, H, W, &rc); SISIC_TRY(rc);
+        SISIC_TRY(conv(a.out, o->p, C, nullptr, 0, H, W, 1, 0, false, false, nullptr, x->p, y->p));
+        release(o);
+        *out = y;
+        return SISIC_OK;
+    }
+
+    int run(const float* sample, float* out, int H, int W) {
+        const sisic_unet_config& cfg = u->cfg;
+        const int n = cfg.n_blocks;
+        int rc = SISIC_OK;
+        std::vector<Buf*> skips;
+
+        Buf* x = make(u->conv_in.cout, H, W, &rc); SISIC_TRY(rc);
+        SISIC_TRY(conv(u->conv_in, sample, cfg.in_channels, nullptr, 0, H, W, 1, 0, false, false, nullptr, nullptr, x->p));
+        x->refs++;                 // held by `x` and by the skip stack
+        skips.push_back(x);
+
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < cfg.layers_per_block; ++j) {
+                Buf* y = nullptr;
+                SISIC_TRY(resnet(u->down_res[i][j], x, nullptr, &y));
+                release(x);
+                x = y;
+                if (cfg.down_attn[i]) {
+                    SISIC_TRY(attention(u->down_attn[i][j], x, &y));
+                    release(x);
+                    x = y;
+                }
+                x->refs++;
+                skips.push_back(x);
+            }
+            if (i != n - 1) {
+                const int Ho = (x->H + 2 - 3) / 2 + 1, Wo = (x->W + 2 - 3) / 2 + 1;
+                Buf* y = make(u->downsamplers[i].cout, Ho, Wo, &rc); SISIC_TRY(rc);
+                SISIC_TRY(conv(u->downsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 2, 0, false, false, nullptr, nullptr, y->p));
+                release(x);
+                x = y;
+                x->refs++;
+                skips.push_back(x);
+            }
+        }
+
+        {
+            Buf* y = nullptr;
+            SISIC_TRY(resnet(u->mid_res[0], x, nullptr, &y)); release(x); x = y;
+            SISIC_TRY(attention(u->mid_attn, x, &y)); release(x); x = y;
+            SISIC_TRY(resnet(u->mid_res[1], x, nullptr, &y)); release(x); x = y;
+        }
+
+        for (int i = 0; i < n; ++i) {
+            const int layers = cfg.layers_per_block + 1;
+            for (int j = 0; j < layers; ++j) {
+                SISIC_REQUIRE(!skips.empty(), "unet: skip stack underflow");
+                Buf* skip = skips.back();
+                skips.pop_back();
+                SISIC_REQUIRE(skip->H == x->H && skip->W == x->W, "unet: skip resolution %dx%d vs %dx%d (H and W must be divisible by %d)",
+                              skip->H, skip->W, x->H, x->W, 1 << (n - 1));
+                Buf* y = nullptr;
+                SISIC_TRY(resnet(u->up_res[i][j], x, skip, &y));
+                release(x);
+                release(skip);
+                x = y;
+                if (cfg.up_attn[i]) {
+                    SISIC_TRY(attention(u->up_attn[i][j], x, &y));
+                    release(x);
+                    x = y;
+                }
+            }
+            if (i != n - 1) {
+                Buf* y = make(u->upsamplers[i].cout, 2 * x->H, 2 * x->W, &rc); SISIC_TRY(rc);
+                SISIC_TRY(conv(u->upsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 1, 1, false, false, nullptr, nullptr, y->p));
+                release(x);
+                x = y;
+            }
+        }
+        SISIC_REQUIRE(skips.empty(), "unet: skip stack not consumed");
+        SISIC_REQUIRE(x->H == H && x->W == W, "unet: output resolution mismatch");
+        SISIC_TRY(gn(x, nullptr, u->norm_out));
+        SISIC_TRY(conv(u->conv_out, x->p, x->C, nullptr, 0, H, W, 1, 0, true, true, nullptr, nullptr, out));
+        release(x);
+        return SISIC_OK;
+    }
+};
+
+int check_shape(sisic_unet* u, int B, int H, int W) {
+    SISIC_REQUIRE(u, "unet: null handle");
+    if (!u->loaded) {
+        set_error("unet: forward called before sisic_unet_load");
+        return SISIC_ESTATE;
+    }
+    SISIC_HIP(hipSetDevice(u->ctx->device));
+    const int div = 1 << (u->cfg.n_blocks - 1);
+    SISIC_REQUIRE(B > 0 && H > 0 && W > 0 && H % div == 0 && W % div == 0,
+                  "unet: sample %dx%dx%d unsupported (H and W must be positive multiples of %d)", B, H, W, div);
+    if (u->ws_B != B || u->ws_H != H || u->ws_W != W) {
+        SISIC_HIP(hipDeviceSynchronize());
+        pool_release_all(u);
+        u->ws_B = B; u->ws_H = H; u->ws_W = W;
+    }
+    return SISIC_OK;
+}
+
+// time embedding + all time_emb_proj rows for `rows` timesteps (t_vals already on the device)
+int time_embed(sisic_unet* u, int rows, hipStream_t s) {
+    SISIC_TRY(launch_temb_mlp(u->ctx, u->t_vals, rows, u->d_freqs, u->cfg.n_freqs, u->w1t, u->rawp(u->temb_b1), u->w2t,
+                              u->rawp(u->temb_b2), u->hidden, u->temb_act, s));
+    SISIC_TRY(launch_linear_t(u->ctx, u->temb_act, rows, u->hidden, u->tproj_wt, u->tproj_b, u->tproj_R, u->tproj, s));
+    return SISIC_OK;
+}
+
+int run_forward(sisic_unet* u, const float* sample, const float* tproj, int tproj_stride, float* out, int B, int H,
+                int W, hipStream_t s) {
+    Fwd f{u, s, B, tproj, tproj_stride, {}};
+    const int rc = f.run(sample, out, H, W);
+    for (auto& b : f.bufs)
+        if (b->p) pool_put(u, b->p);   // error paths: hand everything back
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sisic_unet_create(sisic_ctx* ctx, const sisic_unet_config* cfg, sisic_unet** out) {
+    SISIC_REQUIRE(ctx && cfg && out, "unet_create: null argument");
+    *out = nullptr;
+    SISIC_REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= 8, "unet_create: n_blocks %d", cfg->n_blocks);
+    SISIC_REQUIRE(cfg->layers_per_block >= 1, "unet_create: layers_per_block");
+    SISIC_REQUIRE(cfg->in_channels > 0 && cfg->out_channels > 0, "unet_create: channels");
+    SISIC_REQUIRE(cfg->norm_groups > 0 && cfg->head_dim == 8, "unet_create: head_dim must be 8, groups > 0");
+    SISIC_REQUIRE(cfg->freqs && cfg->n_freqs * 2 == cfg->block_out_channels[0], "unet_create: freqs table must hold block_out_channels[0]/2 entries");
+    for (int i = 0; i < cfg->n_blocks; ++i)
+        SISIC_REQUIRE(cfg->block_out_channels[i] > 0 && cfg->block_out_channels[i] % cfg->norm_groups == 0 &&
+                          cfg->block_out_channels[i] % cfg->head_dim == 0,
+                      "unet_create: block_out_channels[%d]=%d", i, cfg->block_out_channels[i]);
+    auto* u = new sisic_unet();
+    u->ctx = ctx;
+    u->cfg = *cfg;
+    u->freqs.assign(cfg->freqs, cfg->freqs + cfg->n_freqs);
+    u->cfg.freqs = nullptr;
+    const int rc = describe(u);
+    if (rc != SISIC_OK) { delete u; return rc; }
+    *out = u;
+    return SISIC_OK;
+}
+
+int sisic_unet_destroy(sisic_unet* u) {
+    if (!u) return SISIC_OK;
+    (void)hipDeviceSynchronize();
+    pool_release_all(u);
+    for (auto p : u->owned) (void)hipFree(p);
+    for (float* p : {u->raw, u->t_vals, u->temb_act, u->tproj, u->gn_scale, u->gn_shift, u->eps_buf})
+        if (p) (void)hipFree(p);
+    if (u->stage_host) (void)hipHostFree(u->stage_host);
+    for (auto e : u->stage_ev)
+        if (e) (void)hipEventDestroy(e);
+    delete u;
+    return SISIC_OK;
+}
+
+int sisic_unet_num_tensors(const sisic_unet* u) { return u ? (int)u->names.size() : 0; }
+
+const char* sisic_unet_tensor_name(const sisic_unet* u, int i) {
+    if (!u || i < 0 || i >= (int)u->names.size()) return nullptr;
+    return u->names[i].c_str();
+}
+
+int sisic_unet_load(sisic_unet* u, int n, const char* const* names, const float* const* host_ptrs,
+                    const int64_t* numels) {
+    SISIC_REQUIRE(u && names && host_ptrs && numels, "unet_load: null argument");
+    SISIC_REQUIRE(n == (int)u->names.size(), "unet_load: state dict has %d tensors, expected %d", n, (int)u->names.size());
+    SISIC_HIP(hipSetDevice(u->ctx->device));
+    if (!u->raw) {
+        void* p = nullptr;
+        SISIC_HIP(hipMalloc(&p, u->raw_floats * sizeof(float)));
+        u->raw = static_cast<float*>(p);
+    }
+    SISIC_HIP(hipMemset(u->raw, 0, u->raw_floats * sizeof(float)));
+    std::vector<char> seen(u->names.size(), 0);
+    for (int i = 0; i < n; ++i) {
+        SISIC_REQUIRE(names[i] && host_ptrs[i], "unet_load: entry %d is null", i);
+        auto it = u->index.find(names[i]);
+        SISIC_REQUIRE(it != u->index.end(), "unet_load: unexpected key '%s'", names[i]);
+        const int idx = it->second;
+        SISIC_REQUIRE(!seen[idx], "unet_load: duplicate key '%s'", names[i]);
+        SISIC_REQUIRE(numels[i] == u->numels[idx], "unet_load: '%s' has %lld elements, expected %lld", names[i],
+                      (long long)numels[i], (long long)u->numels[idx]);
+        seen[idx] = 1;
+        SISIC_HIP(hipMemcpy(u->raw + u->offsets[idx], host_ptrs[i], (size_t)numels[i] * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // (re)build derived buffers
+    for (auto p : u->owned) (void)hipFree(p);
+    u->owned.clear();
+    u->loaded = false;
+    SISIC_TRY(prepare_all(u));
+    u->loaded = true;
+    return SISIC_OK;
+}
+
+int sisic_unet_forward(sisic_unet* u, const float* sample, const int64_t* timesteps, float* out, int B, int H, int W,
+                       void* stream) {
+    SISIC_REQUIRE(u && sample && timesteps && out, "unet_forward: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SISIC_TRY(check_shape(u, B, H, W));
+    SISIC_TRY(ensure_rows(u, (size_t)B, (size_t)B));
+    std::vector<float> tv(B);
+    bool uniform = true;
+    for (int b = 0; b < B; ++b) {
+        tv[b] = (float)timesteps[b];
+        uniform = uniform && timesteps[b] == timesteps[0];
+    }
+    const int rows = uniform ? 1 : B;
+    SISIC_TRY(stage_upload(u, tv.data(), (size_t)rows, u->t_vals, s));
+    SISIC_TRY(time_embed(u, rows, s));
+    return run_forward(u, sample, u->tproj, uniform ? 0 : u->tproj_R, out, B, H, W, s);
+}
+
+int sisic_sample(sisic_unet* u, float* x, int B, int H, int W, int T, const int64_t* timesteps, const float* coef,
+                 float clip, const float* noise, float* traj, uint8_t* out_u8, const volatile int* cancel,
+                 int* steps_done, void* stream) {
+    SISIC_REQUIRE(u && x && timesteps && coef && T > 0, "sample: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (steps_done) *steps_done = 0;
+    SISIC_TRY(check_shape(u, B, H, W));
+    SISIC_TRY(ensure_rows(u, (size_t)T, (size_t)B));
+    const int C = u->cfg.in_channels;
+    SISIC_REQUIRE(u->cfg.out_channels == C, "sample: in/out channels differ");
+    const size_t n = (size_t)B * C * H * W;
+    SISIC_TRY(grow(&u->eps_buf, &u->eps_floats, n));
+
+    // every step's time embedding and time_emb_proj rows in one batch before the loop
+    std::vector<float> tv(T);
+    for (int i = 0; i < T; ++i) tv[i] = (float)timesteps[i];
+    SISIC_TRY(stage_upload(u, tv.data(), (size_t)T, u->t_vals, s));
+    SISIC_TRY(time_embed(u, T, s));
+
+    size_t zi = 0;
+    for (int i = 0; i < T; ++i) {
+        if (cancel) {
+            if ((i & 7) == 0) SISIC_HIP(hipStreamSynchronize(s));   // bound the run-ahead so a stop request takes effect
+            if (*cancel) {
+                SISIC_HIP(hipStreamSynchronize(s));
+                set_error("sample: cancelled after %d of %d steps", i, T);
+                return SISIC_ECANCEL;
+            }
+        }
+        SISIC_TRY(run_forward(u, x, u->tproj + (size_t)i * u->tproj_R, 0, u->eps_buf, B, H, W, s));
+        const float* c = coef + (size_t)i * 5;
+        const float* z = nullptr;
+        if (noise && c[4] != 0.0f) z = noise + (zi++) * n;
+        SISIC_TRY(launch_ddpm_step(u->ctx, u->eps_buf, x, z, x, (int64_t)n, c[0], c[1], c[2], c[3], c[4], clip, s));
+        if (traj) SISIC_HIP(hipMemcpyAsync(traj + (size_t)i * n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (steps_done) *steps_done = i + 1;
+    }
+    if (out_u8) SISIC_TRY(launch_denorm_u8(u->ctx, x, out_u8, B, C, H, W, s));
+    return SISIC_OK;
+}
+
+}  // extern "C"

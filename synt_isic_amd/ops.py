@@ -1,0 +1,150 @@
+"""Thin torch-tensor wrappers over the single-operator entry points of libsisic_hip.so.
+
+torch is plumbing here (device memory + the current HIP stream); every function
+passes raw device pointers to the C ABI.  Tensors must be contiguous fp32 on an
+MI355X (``cuda``) device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, check
+
+_ctx_by_device = {}
+
+
+def context(device: torch.device) -> C.c_void_p:
+    """One ``sisic_ctx`` per device, created on first use."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"synt_isic_amd runs on MI355X (torch device 'cuda'); got '{device}'. There is no CPU path.")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _ctx_by_device:
+        lib = _lib.load()
+        h = C.c_void_p()
+        check(lib.sisic_create(idx, C.byref(h)))
+        _ctx_by_device[idx] = h
+    return _ctx_by_device[idx]
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor], name: str = "tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous fp32 tensor on the GPU (got {t.dtype}, {t.device}, "
+                         f"contiguous={t.is_contiguous()})")
+    return t.data_ptr()
+
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW -> the kernel's [Cin_pad][k*k][Cout_pad] layout (sisic_conv_pack_weights)."""
+    lib = _lib.load()
+    cout, cin, k, k2 = w.shape
+    assert k == k2
+    n = lib.sisic_conv_packed_numel(cout, cin, k)
+    if n < 0:
+        raise ValueError(f"unsupported conv weight shape {tuple(w.shape)}")
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.sisic_conv_pack_weights(context(w.device), _ptr(w, "weight"), cout, cin, k, out.data_ptr(),
+                                      _stream(w.device)))
+    return out
+
+
+def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bias=None, x2=None, stride=1,
+           upsample=False, gn_scale=None, gn_shift=None, gn_silu=False, chan_bias=None, residual=None,
+           relu=False, tile_cfg=0) -> torch.Tensor:
+    lib = _lib.load()
+    B, c0, H, W = x.shape
+    c1 = 0 if x2 is None else x2.shape[1]
+    Hc, Wc = (2 * H, 2 * W) if upsample else (H, W)
+    pad = ksize // 2
+    Ho = (Hc + 2 * pad - ksize) // stride + 1
+    Wo = (Wc + 2 * pad - ksize) // stride + 1
+    out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    a = ConvArgs()
+    a.in0 = _ptr(x, "x"); a.in1 = _ptr(x2, "x2"); a.c0 = c0; a.c1 = c1
+    a.B = B; a.Hin = H; a.Win = W
+    a.upsample = int(upsample); a.ksize = ksize; a.stride = stride
+    a.w_packed = _ptr(w_packed, "w_packed"); a.bias = _ptr(bias, "bias"); a.Cout = cout
+    a.gn_scale = _ptr(gn_scale, "gn_scale"); a.gn_shift = _ptr(gn_shift, "gn_shift"); a.gn_silu = int(gn_silu)
+    a.chan_bias = _ptr(chan_bias, "chan_bias"); a.chan_bias_stride = cout if chan_bias is not None and chan_bias.dim() == 2 and chan_bias.shape[0] == B else 0
+    a.residual = _ptr(residual, "residual"); a.relu = int(relu)
+    a.out = out.data_ptr(); a.tile_cfg = tile_cfg
+    check(lib.sisic_conv2d(context(x.device), C.byref(a), _stream(x.device)))
+    return out
+
+
+def groupnorm_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                    x2: Optional[torch.Tensor] = None):
+    lib = _lib.load()
+    B, c0 = x.shape[0], x.shape[1]
+    c1 = 0 if x2 is None else x2.shape[1]
+    HW = x[0, 0].numel()
+    scale = torch.empty((B, c0 + c1), dtype=torch.float32, device=x.device)
+    shift = torch.empty_like(scale)
+    check(lib.sisic_groupnorm_stats(context(x.device), _ptr(x, "x"), c0, _ptr(x2, "x2"), c1, B, HW, groups,
+                                    float(eps), _ptr(gamma, "gamma"), _ptr(beta, "beta"), scale.data_ptr(),
+                                    shift.data_ptr(), _stream(x.device)))
+    return scale, shift
+
+
+def attention(qkv: torch.Tensor, head_dim: int = 8) -> torch.Tensor:
+    """qkv [B,3C,N] -> [B,C,N]."""
+    lib = _lib.load()
+    B, C3, N = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty((B, Cc, N), dtype=torch.float32, device=qkv.device)
+    check(lib.sisic_attention(context(qkv.device), _ptr(qkv, "qkv"), out.data_ptr(), B, Cc, N, head_dim,
+                              _stream(qkv.device)))
+    return out
+
+
+def ddpm_step(eps: torch.Tensor, x: torch.Tensor, z: Optional[torch.Tensor], coef, clip: float = 1.0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """coef = (sqrt_beta_prod, sqrt_alpha_prod, c0, c1, sigma)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(x)
+    sb, sa, c0, c1, sigma = (float(v) for v in coef)
+    check(lib.sisic_ddpm_step(context(x.device), _ptr(eps, "eps"), _ptr(x, "x"), _ptr(z, "z"), _ptr(out, "out"),
+                              x.numel(), sb, sa, c0, c1, sigma, float(clip), _stream(x.device)))
+    return out
+
+
+def denorm_u8(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device)
+    check(lib.sisic_denorm_u8(context(x.device), _ptr(x, "x"), out.data_ptr(), B, Cc, H, W, _stream(x.device)))
+    return out
+
+
+_KINDS = {"conv3x3": 0, "conv1x1": 1, "groupnorm": 2, "attention": 3, "ddpm_step": 4, "other": 5}
+
+
+def profile_enable(device, on: bool) -> None:
+    check(_lib.load().sisic_profile_enable(context(device), int(on)))
+
+
+def profile_reset(device) -> None:
+    check(_lib.load().sisic_profile_reset(context(device)))
+
+
+def profile_read(device) -> dict:
+    """{kind: {"ms", "launches", "bytes", "flops"}} accumulated since the last reset (synchronises)."""
+    lib = _lib.load()
+    out = {}
+    for name, kind in _KINDS.items():
+        ms, by, fl = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int64()
+        check(lib.sisic_profile_read(context(device), kind, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)))
+        out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value, "flops": fl.value}
+    return out

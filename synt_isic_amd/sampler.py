@@ -1,0 +1,187 @@
+"""The T-step reverse-diffusion sampler: ``generate(seed, class_name, T)``.
+
+Product-side equivalent of ``ImageGenerator.generate_single_image``
+(core/generator/image_generator.py:308-500): seed policy (:586-592, :626-637),
+initial noise and ``noise_hash`` (:369-389), the loop (:395-403) -- executed by
+``sisic_sample`` in libsisic_hip.so without returning to Python between steps --
+trajectory capture (:406-407) and de-normalisation to uint8 HWC (:441-447).
+
+Noise contract (a defined extension): image b owns one CPU
+``torch.Generator().manual_seed(seed_b)``; ``x_T[b]`` is drawn first, then ``z_t[b]``
+for every step with t > 0 in loop order.  Results are independent of the batch an
+image is sampled in and of how images are sharded over GPUs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .scheduler import HipDDPMScheduler
+from .unet import HipUNet2DModel
+
+ISIC_CLASSES = ("MEL", "NV", "BCC", "AKIEC", "BKL", "DF", "VASC")   # xai/XAI.py:196
+
+
+def class_seed_offset(class_name: str) -> int:
+    """image_generator.py:586-592 -- 31-bit md5 offset per class."""
+    h = hashlib.md5(class_name.encode("utf-8")).hexdigest()
+    return int(h[:8], 16) & 0x7FFFFFFF
+
+
+def image_seed(base_seed: int, class_name: str, index: int) -> int:
+    """image_generator.py:626-631."""
+    return (int(base_seed) + class_seed_offset(class_name) + int(index)) & 0x7FFFFFFF
+
+
+def noise_hash(x_T: torch.Tensor) -> str:
+    """image_generator.py:383-389 -- sha256 of the fp32 bytes of x_T, first 16 hex digits."""
+    return hashlib.sha256(x_T.detach().to("cpu").contiguous().numpy().tobytes()).hexdigest()[:16]
+
+
+def draw_noise(seeds: Sequence[int], n_noise_steps: int, chw: Tuple[int, int, int],
+               pin: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Host noise per the contract above: x_T [B,C,H,W] and z [n_noise_steps,B,C,H,W]."""
+    B = len(seeds)
+    x_T = torch.empty((B,) + tuple(chw), dtype=torch.float32)
+    z = torch.empty((n_noise_steps, B) + tuple(chw), dtype=torch.float32, pin_memory=pin)
+    for b, s in enumerate(seeds):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(int(s))
+        x_T[b] = torch.randn((1,) + tuple(chw), generator=g)[0]
+        if n_noise_steps:
+            # one draw of n*numel values == n consecutive draws of numel (numel is a multiple of 16)
+            z[:, b] = torch.randn((n_noise_steps,) + tuple(chw), generator=g)
+    return x_T, z
+
+
+@dataclass
+class SampleResult:
+    images: torch.Tensor                       # uint8 [B,H,W,3] on the GPU
+    latents: torch.Tensor                      # fp32 [B,3,H,W] final x_0 on the GPU
+    trajectory: Optional[torch.Tensor] = None  # fp32 [T,B,3,H,W] on the GPU
+    seeds: List[int] = field(default_factory=list)
+    noise_hashes: List[str] = field(default_factory=list)
+    timesteps: List[int] = field(default_factory=list)
+    steps_done: int = 0
+
+
+@torch.no_grad()
+def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch.Tensor,
+                      noise: Optional[torch.Tensor], *, return_trajectory: bool = False,
+                      cancel_flag: Optional[C.c_int] = None) -> SampleResult:
+    """x_T: GPU fp32 [B,C,H,W]; noise: GPU fp32 [n_noise,B,C,H,W] or None (no noise added)."""
+    lib = _lib.load()
+    dev = x_T.device
+    if dev.type != "cuda":
+        raise RuntimeError("the sampling loop runs on MI355X only")
+    B, Cc, H, W = x_T.shape
+    ts = scheduler.timesteps.to(torch.int64).contiguous()
+    T = ts.numel()
+    coef = scheduler.coefficient_table().contiguous()
+    n_noise = int((coef[:, 4] != 0).sum())
+    if noise is not None:
+        if tuple(noise.shape) != (n_noise, B, Cc, H, W) or noise.device != dev or noise.dtype != torch.float32:
+            raise ValueError(f"noise must be fp32 {(n_noise, B, Cc, H, W)} on {dev}, got {tuple(noise.shape)}")
+        noise = noise.contiguous()
+    x = x_T.to(torch.float32).contiguous().clone()
+    traj = torch.empty((T, B, Cc, H, W), dtype=torch.float32, device=dev) if return_trajectory else None
+    out_u8 = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=dev)
+    done = C.c_int(0)
+    clip = scheduler.config.clip_sample_range if scheduler.config.clip_sample else 0.0
+    rc = lib.sisic_sample(model.handle, x.data_ptr(), B, H, W, T,
+                          C.cast(ts.data_ptr(), _lib.c_int64_p), C.cast(coef.data_ptr(), _lib.c_float_p),
+                          float(clip), noise.data_ptr() if noise is not None else None,
+                          traj.data_ptr() if traj is not None else None, out_u8.data_ptr(),
+                          C.byref(cancel_flag) if cancel_flag is not None else None, C.byref(done),
+                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != _lib.SISIC_ECANCEL:
+        check(rc)
+    return SampleResult(images=out_u8, latents=x, trajectory=traj, timesteps=[int(t) for t in ts],
+                        steps_done=done.value)
+
+
+class Sampler:
+    """Holds one loaded UNet per class, like ``ModelManager.loaded_models`` (model_manager.py:19-171)."""
+
+    def __init__(self, device="cuda", beta_schedule: str = "squaredcos_cap_v2"):
+        self.device = torch.device(device)
+        self.beta_schedule = beta_schedule
+        self.models: Dict[str, HipUNet2DModel] = {}
+        self.cancel = C.c_int(0)          # cooperative stop flag (image_generator.py:320,396)
+
+    def add_model(self, class_name: str, state_dict: Dict[str, torch.Tensor], **unet_kwargs) -> HipUNet2DModel:
+        m = HipUNet2DModel(**unet_kwargs)
+        m.load_state_dict(state_dict)
+        m = m.to(self.device)
+        m.eval()
+        self.models[class_name] = m
+        return m
+
+    def create_scheduler(self, T: int) -> HipDDPMScheduler:
+        """model_manager.py:196-212."""
+        s = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule=self.beta_schedule)
+        s.set_timesteps(max(1, min(1000, int(T))))
+        return s
+
+    def request_stop(self) -> None:
+        self.cancel.value = 1
+
+    def generate_seeds(self, class_name: str, seeds: Sequence[int], T: int, size: Tuple[int, int] = (128, 128),
+                       return_trajectory: bool = False) -> SampleResult:
+        if class_name not in self.models:
+            raise KeyError(f"no model loaded for class '{class_name}'")
+        model = self.models[class_name]
+        sched = self.create_scheduler(T)
+        n_noise = sum(1 for t in sched.timesteps if int(t) > 0)
+        H, W = size
+        x_T, z = draw_noise(seeds, n_noise, (model.config.in_channels, H, W), pin=True)
+        hashes = [noise_hash(x_T[b:b + 1]) for b in range(len(seeds))]
+        res = run_sampling_loop(model, sched, x_T.to(self.device), z.to(self.device, non_blocking=True),
+                                return_trajectory=return_trajectory, cancel_flag=self.cancel)
+        res.seeds = [int(s) for s in seeds]
+        res.noise_hashes = hashes
+        return res
+
+    def generate(self, seed: int, class_name: str, T: int, *, count: int = 1, size: Tuple[int, int] = (128, 128),
+                 return_trajectory: bool = False, seed_is_base: bool = False):
+        """``generate(seed, class, T)``: returns (uint8 [count,H,W,3] numpy, trajectory list | None).
+
+        seed_is_base=False: image i uses ``manual_seed(seed + i)`` directly (the literal call);
+        seed_is_base=True: ``seed`` is the GUI's base seed and image i uses
+        ``(seed + md5_offset(class) + i) & 0x7fffffff`` (image_generator.py:626-631).
+        Always returns a tuple (the reference's bare ``return False`` on early exit is a latent bug).
+        """
+        if seed_is_base:
+            seeds = [image_seed(seed, class_name, i) for i in range(count)]
+        else:
+            seeds = [(int(seed) + i) & 0x7FFFFFFF for i in range(count)]
+        res = self.generate_seeds(class_name, seeds, T, size, return_trajectory)
+        images = res.images.cpu().numpy()
+        traj = None
+        if return_trajectory:
+            # list of per-step (B,3,H,W) tensors, the shape xai_integration.py consumes
+            traj = [res.trajectory[i] for i in range(res.steps_done)]
+        return images, traj
+
+
+_default_sampler: Optional[Sampler] = None
+
+
+def generate(seed: int, class_name: str, T: int, **kwargs):
+    """Module-level convenience over a process-wide ``Sampler`` whose models were registered with
+    ``default_sampler().add_model(...)``."""
+    return default_sampler().generate(seed, class_name, T, **kwargs)
+
+
+def default_sampler() -> Sampler:
+    global _default_sampler
+    if _default_sampler is None:
+        _default_sampler = Sampler()
+    return _default_sampler

@@ -1,0 +1,49 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def anchors():
+    with open(os.path.join(GOLDEN, "anchors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def synthetic_sd():
+    from synt_isic_amd.weights import synthetic_unet_state_dict
+    return synthetic_unet_state_dict()
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

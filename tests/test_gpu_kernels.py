@@ -1,0 +1,323 @@
+"""Per-kernel parity: each HIP kernel, called through the C ABI, against the CPU oracle's torch op.
+
+Tolerance: fp32 kernels max-abs <= 2e-5 * max(1, |ref|_inf) against a float64
+evaluation of the same op; the scheduler step, the de-normalisation and everything integer are bit-exact.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _close(got: torch.Tensor, ref64: torch.Tensor, tol=2e-5, what=""):
+    got = got.detach().cpu().double()
+    bound = tol * max(1.0, ref64.abs().max().item())
+    err = (got - ref64).abs().max().item()
+    assert got.shape == ref64.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref64.shape)}"
+    assert err <= bound, f"{what}: max abs err {err:.3e} > {bound:.3e}"
+
+
+def _conv_ref(x, w, bias=None, x2=None, stride=1, upsample=False, gn=None, gn_silu=False, chan_bias=None,
+              residual=None, relu=False):
+    """float64 restatement with the oracle's torch ops."""
+    x = x.double()
+    if x2 is not None:
+        x = torch.cat([x, x2.double()], dim=1)
+    if gn is not None:
+        scale, shift = gn
+        x = x * scale.double()[:, :, None, None] + shift.double()[:, :, None, None]
+        if gn_silu:
+            x = F.silu(x)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    k = w.shape[-1]
+    y = F.conv2d(x, w.double(), None if bias is None else bias.double(), stride=stride, padding=k // 2)
+    if chan_bias is not None:
+        y = y + chan_bias.double()[:, :, None, None]
+    if residual is not None:
+        y = y + residual.double()
+    if relu:
+        y = F.relu(y)
+    return y
+
+
+def _run_conv(x, w, cfg, **kw):
+    from synt_isic_amd import ops
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    wp = ops.pack_conv_weight(d(w))
+    gn = kw.get("gn")
+    return ops.conv2d(d(x), wp, w.shape[0], w.shape[-1], bias=d(kw.get("bias")), x2=d(kw.get("x2")),
+                      stride=kw.get("stride", 1), upsample=kw.get("upsample", False),
+                      gn_scale=d(gn[0]) if gn else None, gn_shift=d(gn[1]) if gn else None,
+                      gn_silu=kw.get("gn_silu", False), chan_bias=d(kw.get("chan_bias")),
+                      residual=d(kw.get("residual")), relu=kw.get("relu", False), tile_cfg=cfg)
+
+
+# (cfg, H, W) -- natural shapes for each tile configuration plus ragged ones that exercise the masks
+CONV3_S1 = [(1, 64, 64), (1, 12, 70), (2, 32, 32), (2, 20, 40), (3, 16, 16), (3, 24, 24), (4, 8, 8), (4, 9, 5),
+            (5, 16, 16), (0, 64, 64), (0, 8, 8)]
+
+
+@pytest.mark.parametrize("cfg,H,W", CONV3_S1)
+def test_conv3x3_plain(cfg, H, W):
+    x = _rand(2, 16, H, W, seed=1)
+    w = _rand(64, 16, 3, 3, seed=2, scale=0.1)
+    b = _rand(64, seed=3)
+    _close(_run_conv(x, w, cfg, bias=b), _conv_ref(x, w, b), what=f"conv3x3 cfg{cfg} {H}x{W}")
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 64), (64, 3), (19, 70), (8, 128), (130, 64)])
+def test_conv3x3_channel_edges(cin, cout):
+    x = _rand(2, cin, 16, 32, seed=4)
+    w = _rand(cout, cin, 3, 3, seed=5, scale=0.1)
+    b = _rand(cout, seed=6)
+    for cfg in (0, 1, 4):
+        _close(_run_conv(x, w, cfg, bias=b), _conv_ref(x, w, b), what=f"conv3x3 {cin}->{cout} cfg{cfg}")
+
+
+def test_conv3x3_no_bias_and_identity_weight():
+    """A = I with an asymmetric input: catches a swapped MFMA row/column map."""
+    C = 64
+    x = _rand(1, C, 8, 8, seed=7)
+    w = torch.zeros(C, C, 3, 3)
+    for c in range(C):
+        w[c, c, 1, 1] = 1.0
+    for cfg in (1, 2, 3, 4, 5):
+        got = _run_conv(x, w, cfg).cpu()
+        assert torch.equal(got, x), f"identity conv cfg{cfg} is not exact"
+    # shifted identity: out[c] = in[(c+1) % C] moved one pixel right
+    w2 = torch.zeros(C, C, 3, 3)
+    for c in range(C):
+        w2[c, (c + 1) % C, 1, 0] = 1.0
+    want = F.conv2d(x, w2, padding=1)
+    for cfg in (1, 4):
+        assert torch.equal(_run_conv(x, w2, cfg).cpu(), want)
+
+
+@pytest.mark.parametrize("cfg,H,W", [(1, 64, 64), (2, 32, 32), (3, 16, 16), (4, 8, 8), (2, 20, 24)])
+def test_conv3x3_fused_everything(cfg, H, W):
+    """two sources whose seam falls inside a channel chunk + GN/SiLU prologue + time bias + residual."""
+    B, c0, c1, cout = 2, 20, 12, 64
+    x, x2 = _rand(B, c0, H, W, seed=8), _rand(B, c1, H, W, seed=9)
+    w = _rand(cout, c0 + c1, 3, 3, seed=10, scale=0.1)
+    b = _rand(cout, seed=11)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=12), 0.3 * _rand(B, c0 + c1, seed=13))
+    cb = _rand(B, cout, seed=14)
+    res = _rand(B, cout, H, W, seed=15)
+    kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True, chan_bias=cb, residual=res)
+    _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"fused conv cfg{cfg}")
+    kw = dict(bias=b, x2=x2, gn=gn, gn_silu=False, relu=True)
+    _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"fused conv (no silu, relu) cfg{cfg}")
+    # one chan_bias row shared by every sample (the sampler's per-step time embedding)
+    kw = dict(bias=b, x2=x2, chan_bias=cb[0])
+    ref = _conv_ref(x, w, bias=b, x2=x2, chan_bias=cb[0:1].expand(B, -1))
+    _close(_run_conv(x, w, cfg, **kw), ref, what=f"broadcast chan_bias cfg{cfg}")
+
+
+def test_gn_prologue_keeps_padding_zero():
+    """Zero padding is applied AFTER GroupNorm+SiLU: a constant shift must not leak into the border."""
+    x = torch.zeros(1, 8, 8, 8)
+    w = torch.ones(64, 8, 3, 3)
+    gn = (torch.ones(1, 8), torch.full((1, 8), 2.0))
+    got = _run_conv(x, w, 4, gn=gn, gn_silu=False).cpu()
+    assert got[0, 0, 4, 4].item() == pytest.approx(8 * 9 * 2.0)
+    assert got[0, 0, 0, 0].item() == pytest.approx(8 * 4 * 2.0)     # corner sees 4 in-bounds taps only
+
+
+@pytest.mark.parametrize("cfg,H,W", [(0, 32, 32), (0, 16, 16), (0, 8, 8), (1, 32, 32), (2, 16, 16), (3, 8, 8), (4, 4, 4),
+                                     (2, 10, 14)])
+def test_conv3x3_upsample(cfg, H, W):
+    x = _rand(2, 24, H, W, seed=16)
+    w = _rand(64, 24, 3, 3, seed=17, scale=0.1)
+    b = _rand(64, seed=18)
+    _close(_run_conv(x, w, cfg, bias=b, upsample=True), _conv_ref(x, w, b, upsample=True),
+           what=f"upsample conv cfg{cfg} {H}x{W}")
+
+
+@pytest.mark.parametrize("cfg,H,W", [(0, 64, 64), (0, 32, 32), (0, 16, 16), (11, 64, 64), (12, 32, 32), (13, 16, 16),
+                                     (11, 20, 36), (13, 6, 10)])
+def test_conv3x3_stride2(cfg, H, W):
+    x = _rand(2, 16, H, W, seed=19)
+    w = _rand(64, 16, 3, 3, seed=20, scale=0.1)
+    b = _rand(64, seed=21)
+    _close(_run_conv(x, w, cfg, bias=b, stride=2), _conv_ref(x, w, b, stride=2), what=f"stride-2 conv cfg{cfg}")
+
+
+@pytest.mark.parametrize("cfg,H,W", [(0, 16, 16), (0, 8, 8), (21, 16, 16), (21, 9, 7), (22, 8, 8), (22, 5, 5),
+                                     (23, 16, 16), (23, 12, 20)])
+def test_conv1x1(cfg, H, W):
+    B, c0, c1, cout = 2, 40, 24, 96
+    x, x2 = _rand(B, c0, H, W, seed=22), _rand(B, c1, H, W, seed=23)
+    w = _rand(cout, c0 + c1, 1, 1, seed=24, scale=0.2)
+    b = _rand(cout, seed=25)
+    res = _rand(B, cout, H, W, seed=26)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=27), 0.3 * _rand(B, c0 + c1, seed=28))
+    _close(_run_conv(x, w, cfg, bias=b, x2=x2), _conv_ref(x, w, b, x2=x2), what=f"conv1x1 cfg{cfg}")
+    kw = dict(bias=b, x2=x2, gn=gn, gn_silu=False, residual=res)
+    _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"conv1x1 fused cfg{cfg}")
+
+
+def test_conv_reference_layer_shapes():
+    """The distinct (Cin, Cout, resolution) classes of the reference UNet at 64x64, B=1."""
+    shapes = [(3, 64, 64), (64, 64, 64), (192, 64, 64), (128, 128, 32), (384, 128, 32), (256, 256, 16),
+              (512, 256, 16), (256, 256, 8), (512, 256, 8), (64, 3, 64)]
+    for i, (cin, cout, r) in enumerate(shapes):
+        x = _rand(1, cin, r, r, seed=100 + i)
+        w = _rand(cout, cin, 3, 3, seed=200 + i, scale=(cin * 9) ** -0.5)
+        b = _rand(cout, seed=300 + i, scale=0.1)
+        _close(_run_conv(x, w, 0, bias=b), _conv_ref(x, w, b), what=f"layer {cin}->{cout}@{r}")
+
+
+def test_conv_argument_errors():
+    from synt_isic_amd import ops
+    from synt_isic_amd._lib import SisicError
+    x = _rand(1, 8, 8, 8).to(DEV)
+    wp = ops.pack_conv_weight(_rand(64, 8, 3, 3).to(DEV))
+    with pytest.raises(SisicError, match="tile_cfg"):
+        ops.conv2d(x, wp, 64, 3, tile_cfg=99)
+    with pytest.raises(SisicError, match="stride"):
+        ops.conv2d(x, wp, 64, 3, stride=3)
+    with pytest.raises(ValueError):
+        ops.conv2d(x.double(), wp, 64, 3)
+    with pytest.raises(ValueError):
+        ops.pack_conv_weight(_rand(64, 8, 5, 5).to(DEV))
+
+
+# ---------------------------------------------------------------------------------- GroupNorm
+@pytest.mark.parametrize("c0,c1,H,W", [(64, 0, 64, 64), (256, 128, 16, 16), (128, 64, 32, 32), (512, 0, 8, 8),
+                                       (64, 0, 9, 7), (96, 32, 5, 3)])
+def test_groupnorm_stats(c0, c1, H, W):
+    from synt_isic_amd import ops
+    B, G, eps = 3, 32, 1e-5
+    x = _rand(B, c0, H, W, seed=30) * 2.0 + 0.7
+    x2 = (_rand(B, c1, H, W, seed=31) - 1.5) if c1 else None
+    C = c0 + c1
+    gamma, beta = 1.0 + 0.1 * _rand(C, seed=32), 0.1 * _rand(C, seed=33)
+    sc, sh = ops.groupnorm_stats(x.to(DEV), gamma.to(DEV), beta.to(DEV), G, eps, x2.to(DEV) if c1 else None)
+    full = (torch.cat([x, x2], 1) if c1 else x).double()
+    ref = F.group_norm(full, G, gamma.double(), beta.double(), eps)
+    got = full * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=2e-5, what="groupnorm apply")
+    # the fused consumer: conv(SiLU(GN(x))) == oracle composition
+    w = _rand(64, C, 3, 3, seed=34, scale=0.05)
+    wp = ops.pack_conv_weight(w.to(DEV))
+    y = ops.conv2d(x.to(DEV), wp, 64, 3, x2=x2.to(DEV) if c1 else None, gn_scale=sc, gn_shift=sh, gn_silu=True)
+    _close(y, F.conv2d(F.silu(ref), w.double(), padding=1), tol=3e-5, what="GN+SiLU+conv")
+
+
+def test_groupnorm_large_mean_is_stable():
+    """two-pass variance: |mean| >> std must not lose the variance (E[x^2]-mean^2 would)."""
+    from synt_isic_amd import ops
+    x = _rand(1, 32, 16, 16, seed=35) * 1e-2 + 100.0
+    gamma, beta = torch.ones(32), torch.zeros(32)
+    sc, sh = ops.groupnorm_stats(x.to(DEV), gamma.to(DEV), beta.to(DEV), 32, 1e-5)
+    ref = F.group_norm(x.double(), 32, eps=1e-5)
+    got = x.double() * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    assert (got - ref).abs().max().item() < 5e-3      # fp32 input quantisation at |x|=100 dominates
+
+
+# ---------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, heads):
+    B, C3, N = qkv.shape
+    C = C3 // 3
+    d = C // heads
+    q, k, v = qkv.double().reshape(B, 3, heads, d, N).unbind(1)            # [B, heads, d, N]
+    s = torch.einsum("bhdq,bhdk->bhqk", q, k) * d ** -0.5
+    p = torch.softmax(s, dim=-1)
+    o = torch.einsum("bhqk,bhdk->bhdq", p, v)
+    return o.reshape(B, C, N)
+
+
+@pytest.mark.parametrize("N", [64, 256, 100, 33, 1024, 300, 513])
+def test_attention(N):
+    from synt_isic_amd import ops
+    B, C = 2, 256
+    qkv = _rand(B, 3 * C, N, seed=40 + N) * 1.5
+    got = ops.attention(qkv.to(DEV), 8)
+    _close(got, _attn_ref(qkv, C // 8), tol=2e-5, what=f"attention N={N}")
+
+
+def test_attention_online_rescale_branch():
+    """N > 256 runs the online softmax across key blocks; spike a key in the LAST block so the running
+    maximum jumps there and everything accumulated before must be rescaled (and the reverse)."""
+    from synt_isic_amd import ops
+    B, C, N = 1, 64, 768
+    for spike_at in (700, 5):
+        qkv = _rand(B, 3 * C, N, seed=50) * 0.5
+        qkv[:, C:2 * C, spike_at] *= 40.0            # one key with a huge norm
+        got = ops.attention(qkv.to(DEV), 8)
+        ref = _attn_ref(qkv, C // 8)
+        assert torch.isfinite(got).all()
+        _close(got, ref, tol=5e-5, what=f"attention spike at key {spike_at}")
+
+
+def test_attention_rejects_other_head_dims():
+    from synt_isic_amd import ops
+    from synt_isic_amd._lib import SisicError
+    with pytest.raises(SisicError, match="head_dim"):
+        ops.attention(_rand(1, 3 * 64, 16).to(DEV), 16)
+
+
+# ---------------------------------------------------------------------------------- scheduler step
+@pytest.mark.parametrize("schedule,T", [("squaredcos_cap_v2", 50), ("squaredcos_cap_v2", 1000), ("linear", 1000)])
+def test_ddpm_step_bit_exact(schedule, T):
+    from oracle import ddpm as oddpm
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    o = oddpm.DDPMSchedulerOracle(beta_schedule=schedule)
+    o.set_timesteps(T)
+    s = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule=schedule)
+    s.set_timesteps(T)
+    x = _rand(2, 3, 16, 16, seed=60) * 1.3
+    eps = _rand(2, 3, 16, 16, seed=61)
+    z = _rand(2, 3, 16, 16, seed=62)
+    ts = [int(t) for t in s.timesteps]
+    for t in [ts[0], ts[1], ts[len(ts) // 2], ts[-2], ts[-1]]:
+        want = o.step(eps, t, x, noise=z)
+        got = s.step(eps.to(DEV), t, x.to(DEV), variance_noise=z.to(DEV)).prev_sample.cpu()
+        assert torch.equal(got, want), f"t={t}: max diff {(got - want).abs().max().item():.3e}"
+
+
+def test_ddpm_step_tail_and_inplace():
+    from oracle import ddpm as oddpm
+    from synt_isic_amd import ops
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    o = oddpm.DDPMSchedulerOracle(); o.set_timesteps(50)
+    s = HipDDPMScheduler(beta_schedule="squaredcos_cap_v2"); s.set_timesteps(50)
+    n = 4 * 257 + 3                                     # not a multiple of 4: scalar tail
+    x, eps, z = _rand(n, seed=63), _rand(n, seed=64), _rand(n, seed=65)
+    want = o.step(eps, 500, x, noise=z)
+    xd = x.to(DEV)
+    ops.ddpm_step(eps.to(DEV), xd, z.to(DEV), s.step_coefficients(500), 1.0, out=xd)      # in place
+    assert torch.equal(xd.cpu(), want)
+    # misaligned views take the scalar path
+    big = _rand(3 * n + 1, seed=66).to(DEV)
+    xv = big[1:1 + n]
+    got = ops.ddpm_step(eps.to(DEV), xv.contiguous(), z.to(DEV), s.step_coefficients(500), 1.0)
+    assert torch.equal(got.cpu(), o.step(eps, 500, xv.cpu(), noise=z))
+    # generator-driven noise (the reference's call passes none; diffusers draws on the sample's device)
+    g = torch.Generator().manual_seed(5)
+    a = s.step(eps.to(DEV), 500, x.to(DEV), generator=g).prev_sample.cpu()
+    g2 = torch.Generator().manual_seed(5)
+    assert torch.equal(a, o.step(eps, 500, x, generator=g2))
+
+
+def test_denorm_u8_bit_exact():
+    from oracle import sampler as osampler
+    from synt_isic_amd import ops
+    x = _rand(3, 3, 20, 12, seed=70) * 0.8
+    x[0, 0, 0, :8] = torch.tensor([-1.5, -1.0, -0.999, 0.0, 0.5, 0.99999, 1.0, 3.0])
+    x[1, 1, 1, 1] = float("inf"); x[1, 1, 1, 2] = -float("inf")
+    got = ops.denorm_u8(x.to(DEV)).cpu().numpy()
+    assert got.shape == (3, 20, 12, 3) and got.dtype == np.uint8
+    assert np.array_equal(got, osampler.denormalize_to_uint8(x))

@@ -1,0 +1,163 @@
+"""The T-step loop (sisic_sample) against the oracle, the committed trajectory fixture, and -- at
+BASELINE.json's full batch size -- size-independent properties (determinism, batch/shard independence).
+
+Stated tolerances: T=50 trajectory end <= 2e-3 max-abs in [-1,1]; uint8 images within
++-1 LSB on >= 99 % of pixels; integer pieces bit-exact.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def sampler(synthetic_sd):
+    from synt_isic_amd.sampler import Sampler
+    s = Sampler(DEV)
+    s.add_model("NV", synthetic_sd)
+    return s
+
+
+def test_config1_T50_seed0_matches_golden(sampler, golden_dir):
+    """BASELINE config 1: 1 image, 3x64x64, T=50, seed=0, class NV."""
+    g = np.load(os.path.join(golden_dir, "sample_T50_seed0_64.npz"))
+    res = sampler.generate_seeds("NV", [0], T=50, size=(64, 64), return_trajectory=True)
+    assert res.timesteps == list(range(980, -1, -20))               # integer grid, bit-exact
+    assert res.noise_hashes == ["ce480957dd270985"]                 # image_generator.py:383-389 anchor
+    assert res.steps_done == 50
+    traj = res.trajectory.cpu().numpy()                             # [50,1,3,64,64]
+    for i, step in enumerate(g["steps"]):
+        err = np.abs(traj[int(step)] - g["traj"][i]).max()
+        assert err <= 2e-3, f"step {step}: {err:.3e}"
+    assert np.abs(res.latents.cpu().numpy() - g["final"]).max() <= 2e-3
+    img = res.images.cpu().numpy()
+    assert img.shape == (1, 64, 64, 3) and img.dtype == np.uint8
+    assert np.mean(np.abs(img.astype(int) - g["image"].astype(int)) <= 1) >= 0.99
+    # the final image is the de-normalisation of the final latents, bit-exact
+    from oracle import sampler as osampler
+    assert np.array_equal(img, osampler.denormalize_to_uint8(res.latents.cpu()))
+
+
+def test_generate_call_surface(sampler):
+    images, traj = sampler.generate(0, "NV", 6, count=2, size=(32, 32), return_trajectory=True)
+    assert images.shape == (2, 32, 32, 3) and images.dtype == np.uint8
+    assert isinstance(traj, list) and len(traj) == 6 and traj[0].shape == (2, 3, 32, 32)
+    assert float(traj[0].abs().max()) < 10
+    images2, none = sampler.generate(0, "NV", 6, count=2, size=(32, 32))
+    assert none is None and np.array_equal(images, images2)
+    # base-seed semantics of the GUI path: seed_i = (base + md5 offset + i) & 0x7fffffff
+    from synt_isic_amd.sampler import image_seed
+    a, _ = sampler.generate(42, "NV", 4, count=1, size=(32, 32), seed_is_base=True)
+    b = sampler.generate_seeds("NV", [image_seed(42, "NV", 0)], 4, (32, 32)).images.cpu().numpy()
+    assert np.array_equal(a, b)
+    with pytest.raises(KeyError):
+        sampler.generate(0, "MEL", 4)
+
+
+def test_loop_equals_reference_style_python_loop(sampler, synthetic_sd):
+    """The literal loop of image_generator.py:395-403 over the two drop-in objects gives the same
+    latents as the fused in-library loop, and both match the oracle."""
+    from oracle import sampler as osampler
+    from synt_isic_amd.sampler import draw_noise
+    model = sampler.models["NV"]
+    scheduler = sampler.create_scheduler(8)
+    x_T, z = draw_noise([3, 4], 7, (3, 32, 32))
+    latents = x_T.to(DEV)
+    zi = 0
+    with torch.no_grad():
+        for step_idx, t in enumerate(scheduler.timesteps):
+            noise_pred = model(latents, t).sample
+            vn = None
+            if int(t) > 0:
+                vn = z[zi].to(DEV); zi += 1
+            latents = scheduler.step(noise_pred, t, latents, variance_noise=vn).prev_sample
+    res = sampler.generate_seeds("NV", [3, 4], T=8, size=(32, 32))
+    assert torch.equal(res.latents, latents)
+    _, ref, _ = osampler.sample(synthetic_sd, [3, 4], 8, (32, 32))
+    assert (latents.cpu() - ref).abs().max().item() <= 1e-3
+
+
+def test_linear_schedule_variant(sampler, synthetic_sd):
+    """diffusion_generator.py:123-144: beta_schedule='linear', all 1000 train steps (truncated here)."""
+    from oracle import ddpm as oddpm, unet as ounet
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    model = sampler.models["NV"]
+    s = HipDDPMScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear")
+    o = oddpm.DDPMSchedulerOracle(beta_schedule="linear")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 32, 32, generator=g)
+    xr = x.clone()
+    xd = x.to(DEV)
+    for t in list(s.timesteps)[:4]:
+        z = torch.randn(1, 3, 32, 32, generator=g)
+        xd = s.step(model(xd, t).sample, t, xd, variance_noise=z.to(DEV)).prev_sample
+        with torch.no_grad():
+            xr = o.step(ounet.unet_forward(synthetic_sd, xr, int(t)), int(t), xr, noise=z)
+    assert (xd.cpu() - xr).abs().max().item() <= 1e-3
+
+
+def test_batch_and_shard_independence_small(sampler):
+    """An image's chain depends only on its own seed: any batch composition gives bit-identical results
+    (this is what makes the 8-GPU sharding of BASELINE config 3 equal to the single-GPU run)."""
+    seeds = [0, 5, 9, 11]
+    full = sampler.generate_seeds("NV", seeds, T=10, size=(32, 32))
+    for i, s in enumerate(seeds):
+        one = sampler.generate_seeds("NV", [s], T=10, size=(32, 32))
+        assert torch.equal(one.latents[0], full.latents[i])
+        assert torch.equal(one.images[0], full.images[i])
+    a = sampler.generate_seeds("NV", seeds[:2], T=10, size=(32, 32))
+    b = sampler.generate_seeds("NV", seeds[2:], T=10, size=(32, 32))
+    assert torch.equal(torch.cat([a.images, b.images]), full.images)
+
+
+def test_full_batch_properties(sampler):
+    """BASELINE config 2 shape (batch=64, 3x64x64), shortened to 3 steps: determinism, batch independence
+    and the clip invariant |x0_hat| <= 1 => latents stay bounded."""
+    from synt_isic_amd.sampler import draw_noise, run_sampling_loop
+    seeds = list(range(64))
+    sched = sampler.create_scheduler(1000)
+    sched.timesteps = sched.timesteps[:3]                # 999, 998, 997 with the T=1000 spacing
+    x_T, z = draw_noise(seeds, 3, (3, 64, 64))
+    model = sampler.models["NV"]
+    r1 = run_sampling_loop(model, sched, x_T.to(DEV), z.to(DEV), return_trajectory=True)
+    r2 = run_sampling_loop(model, sched, x_T.to(DEV), z.to(DEV))
+    assert r1.steps_done == 3 and torch.equal(r1.latents, r2.latents) and torch.equal(r1.images, r2.images)
+    assert torch.equal(r1.trajectory[-1], r1.latents)
+    assert torch.isfinite(r1.latents).all() and float(r1.latents.abs().max()) < 8.0
+    k = 17
+    rk = run_sampling_loop(model, sched, x_T[k:k + 1].to(DEV), z[:, k:k + 1].contiguous().to(DEV))
+    assert torch.equal(rk.latents[0], r1.latents[k])
+    # x_T itself is untouched by the call (the loop works on a copy)
+    assert torch.equal(x_T, draw_noise(seeds, 0, (3, 64, 64))[0])
+
+
+def test_cancel_flag_stops_the_loop(sampler):
+    from synt_isic_amd.sampler import draw_noise, run_sampling_loop
+    sched = sampler.create_scheduler(50)
+    x_T, z = draw_noise([1], 49, (3, 32, 32))
+    flag = ctypes.c_int(1)                                 # stop requested before the first step
+    res = run_sampling_loop(sampler.models["NV"], sched, x_T.to(DEV), z.to(DEV), cancel_flag=flag)
+    assert res.steps_done == 0
+    assert torch.equal(res.latents.cpu(), x_T)            # nothing was applied
+    flag.value = 0
+    res = run_sampling_loop(sampler.models["NV"], sched, x_T.to(DEV), z.to(DEV), cancel_flag=flag)
+    assert res.steps_done == 50
+
+
+def test_noise_shape_is_validated(sampler):
+    from synt_isic_amd.sampler import draw_noise, run_sampling_loop
+    sched = sampler.create_scheduler(4)
+    x_T, z = draw_noise([1], 2, (3, 32, 32))               # needs 3 noise tensors for T=4
+    with pytest.raises(ValueError, match="noise"):
+        run_sampling_loop(sampler.models["NV"], sched, x_T.to(DEV), z.to(DEV))
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()

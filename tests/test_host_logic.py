@@ -1,0 +1,136 @@
+"""Host-side logic of synt_isic_amd (no GPU): schedule tables, seed policy, noise streams,
+state-dict handling, and the 'no CPU fallback' rule."""
+import pytest
+import torch
+
+from oracle import ddpm as oddpm
+from oracle import sampler as osampler
+from oracle import unet as ounet
+from synt_isic_amd import arch, sampler, scheduler, unet, weights
+
+
+def test_param_spec_matches_oracle():
+    assert list(arch.unet_param_spec().items()) == list(ounet.param_spec().items())
+    assert arch.unet_num_params() == 25_304_963
+
+
+@pytest.mark.parametrize("schedule", ["squaredcos_cap_v2", "linear"])
+def test_scheduler_tables_bit_exact(schedule):
+    a = scheduler.HipDDPMScheduler(num_train_timesteps=1000, beta_schedule=schedule)
+    b = oddpm.DDPMSchedulerOracle(beta_schedule=schedule)
+    assert torch.equal(a.betas, b.betas)
+    assert torch.equal(a.alphas_cumprod, b.alphas_cumprod)
+    assert torch.equal(a.timesteps, b.timesteps)
+    for T in (1000, 50, 7, 1):
+        a.set_timesteps(T)
+        b.set_timesteps(T)
+        assert a.timesteps.dtype == torch.int64
+        assert torch.equal(a.timesteps, b.timesteps)
+        for t in a.timesteps[:: max(1, T // 10)].tolist() + [int(a.timesteps[-1])]:
+            ca = a.step_coefficients(t)
+            cb = b.coefficients(t)
+            assert ca == (cb.sqrt_beta_prod_t, cb.sqrt_alpha_prod_t, cb.pred_original_coeff,
+                          cb.current_sample_coeff, cb.sigma)
+    tab = a.coefficient_table()
+    assert tab.shape == (1, 5) and tab.dtype == torch.float32
+
+
+def test_scheduler_reference_constructor_forms():
+    # model_manager.py:199-202
+    s = scheduler.HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
+    s.set_timesteps(50)
+    assert [int(t) for t in s.timesteps][:3] == [980, 960, 940]
+    assert float(s.timesteps[0]) == 980.0 and int(s.timesteps[-1]) == 0      # XAI.py:744,764 use float()/int()
+    # image_generator.py:292-296
+    scheduler.HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2", prediction_type="epsilon")
+    # diffusion_generator.py:123-128
+    lin = scheduler.HipDDPMScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear")
+    assert len(lin) == 1000 and len(lin.timesteps) == 1000 and int(lin.timesteps[0]) == 999
+    with pytest.raises(NotImplementedError):
+        scheduler.HipDDPMScheduler(prediction_type="v_prediction")
+    with pytest.raises(ValueError):
+        s.set_timesteps(1001)
+
+
+def test_scheduler_step_refuses_cpu():
+    s = scheduler.HipDDPMScheduler(beta_schedule="squaredcos_cap_v2")
+    x = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        s.step(x, 10, x)
+
+
+def test_seed_policy_and_noise_hash():
+    for c in sampler.ISIC_CLASSES:
+        assert sampler.class_seed_offset(c) == osampler.class_seed_offset(c)
+    assert sampler.ISIC_CLASSES == osampler.ISIC_CLASSES
+    assert sampler.image_seed(42, "NV", 5) == osampler.image_seed(42, "NV", 5) == (42 + 1396962837 + 5) & 0x7FFFFFFF
+    x = osampler.initial_noise(0, (1, 3, 64, 64))
+    assert sampler.noise_hash(x) == "ce480957dd270985"
+
+
+def test_noise_streams_match_oracle_and_are_batch_independent():
+    seeds = [0, 7, 123456]
+    x1, z1 = sampler.draw_noise(seeds, 5, (3, 16, 16))
+    x2, z2 = osampler.draw_noise(seeds, 5, (3, 16, 16))
+    assert torch.equal(x1, x2) and torch.equal(z1, z2)
+    xs, zs = sampler.draw_noise([7], 5, (3, 16, 16))
+    assert torch.equal(xs[0], x1[1]) and torch.equal(zs[:, 0], z1[:, 1])
+    assert torch.equal(x1[0:1], osampler.initial_noise(0, (1, 3, 16, 16)))
+
+
+def test_state_dict_strictness_and_legacy_keys():
+    sd = weights.synthetic_unet_state_dict()
+    m = unet.HipUNet2DModel()          # reference's constructor defaults == model_manager.py:175-194
+    m.load_state_dict(sd)
+    assert sum(p.numel() for p in m.parameters()) == 25_304_963
+    assert str(m.device) == "cpu" and m.training is True
+    assert m.eval() is m and m.training is False
+    assert all(not p.requires_grad for p in m.parameters())
+    # strict: a missing key or a wrong shape is an error
+    bad = dict(sd); bad.pop("conv_in.bias")
+    with pytest.raises(RuntimeError, match="missing"):
+        unet.HipUNet2DModel().load_state_dict(bad)
+    bad = dict(sd); bad["extra.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="unexpected"):
+        unet.HipUNet2DModel().load_state_dict(bad)
+    bad = dict(sd); bad["conv_in.weight"] = torch.zeros(64, 3, 1, 1)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        unet.HipUNet2DModel().load_state_dict(bad)
+    # checkpoints from older diffusers spell the attention projections query/key/value/proj_attn
+    legacy = {}
+    for k, v in sd.items():
+        for new, old in (("to_q", "query"), ("to_k", "key"), ("to_v", "value"), ("to_out.0", "proj_attn")):
+            if ".attentions." in k and f".{new}." in k:
+                k = k.replace(f".{new}.", f".{old}.")
+        legacy[k] = v
+    assert any(".query." in k for k in legacy)
+    m2 = unet.HipUNet2DModel()
+    m2.load_state_dict(legacy)
+    assert list(m2.state_dict()) == list(sd)
+
+
+def test_no_cpu_fallback():
+    m = unet.HipUNet2DModel()
+    m.load_state_dict(weights.synthetic_unet_state_dict())
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, 3, 64, 64), 10)
+    with pytest.raises(NotImplementedError):
+        m.train()
+    with pytest.raises(NotImplementedError):
+        unet.HipUNet2DModel(class_embed_type="timestep")
+
+
+def test_frequency_table_matches_oracle():
+    assert torch.equal(unet.timestep_frequencies(64), ounet.timestep_frequencies(64))
+
+
+def test_product_does_not_import_oracle():
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "synt_isic_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{fn} imports the oracle"
