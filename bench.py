@@ -41,7 +41,12 @@ PEAK_HBM_GBPS = 8000.0            # HBM3E spec
 def cpu_baseline(sd, seconds_budget: float = 25.0):
     """The oracle on the host cores: B=8, 3x64x64, consecutive steps from t=999 (2 warm-up, then timed)."""
     from oracle import ddpm as oddpm, unet as ounet
-    n_thr = os.cpu_count() or 1
+    # the box's CPU share, not the host's core count: oversubscribing OpenMP threads stalls the oracle
+    try:
+        n_aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_aff = os.cpu_count() or 1
+    n_thr = max(1, min(n_aff, int(os.environ.get("SISIC_CPU_THREADS", "16"))))
     torch.set_num_threads(n_thr)
     B = 8
     g = torch.Generator().manual_seed(0)
@@ -50,6 +55,7 @@ def cpu_baseline(sd, seconds_budget: float = 25.0):
     sched.set_timesteps(T_FULL)
     ts = [int(t) for t in sched.timesteps]
     done, t_used, i = 0, 0.0, 0
+    t_start = time.perf_counter()
     with torch.no_grad():
         while True:
             t0 = time.perf_counter()
@@ -62,6 +68,8 @@ def cpu_baseline(sd, seconds_budget: float = 25.0):
                 t_used += dt
                 if t_used >= seconds_budget or done >= 20:
                     break
+            if time.perf_counter() - t_start > 3 * seconds_budget and done >= 1:
+                break
     s_per_step = t_used / done
     cpu_model = ""
     try:
@@ -98,6 +106,9 @@ def main():
     from synt_isic_amd.sampler import Sampler, run_sampling_loop
     from synt_isic_amd.weights import synthetic_unet_state_dict
 
+    def log(msg):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     rank, world, local = sdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
@@ -128,6 +139,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
+    log(f"model loaded on {dev}; warm-up {W} steps")
     # warm-up: W untimed steps (also sizes the library workspace)
     if W > 0:
         sched, x_T, z = make_run(W)
@@ -146,6 +158,7 @@ def main():
 
     ms_per_step = elapsed * 1e3 / K
     value = B * world / (ms_per_step * 1e-3 * T_FULL)
+    log(f"timed {K} steps: {ms_per_step:.3f} ms/step -> {value:.3f} images/sec")
 
     roofline = None
     cpu = None
@@ -177,8 +190,10 @@ def main():
             "hbm_frac": gbps / PEAK_HBM_GBPS,
             "per_step_ms": {k: v["ms"] / n_prof for k, v in prof.items()},
         }
+        log(f"conv3x3: {tflops:.1f} TFLOP/s over {c3['launches']} launches")
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(sd)
+            log(f"cpu baseline: {cpu['value']:.5f} images/sec on {cpu['cores']} threads")
 
     if rank == 0:
         line = {
