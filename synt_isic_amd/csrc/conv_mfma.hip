@@ -62,13 +62,14 @@ struct ConvGeom {
     static constexpr int PAD = KS / 2;
     static constexpr int IH = (TH - 1) * STRIDE + KS;
     static constexpr int IW = (TW - 1) * STRIDE + KS;
-    static constexpr int CHS = IH * IW;                       // LDS floats per staged channel
     static constexpr int TPC = NTHR / CIC;                    // threads staging one channel
-    static constexpr int EPT = (CHS + TPC - 1) / TPC;         // input elements per thread per chunk
+    static constexpr int EPT = (IH * IW + TPC - 1) / TPC;     // input elements per thread per chunk
+    static constexpr int CHS = EPT * TPC;                     // LDS floats per staged channel (>= IH*IW, padded so
+                                                              // every thread stores all its EPT elements)
     static constexpr int IN_BUF = ((CIC * CHS + 3) / 4) * 4;  // floats, 16-B multiple
-    static constexpr int W_BUF = CIC * KK * CO_TILE;
-    static constexpr int W_F4 = W_BUF / 4;
+    static constexpr int W_F4 = CIC * KK * CO_TILE / 4;       // float4 per weight slab
     static constexpr int W_F4_PT = (W_F4 + NTHR - 1) / NTHR;
+    static constexpr int W_BUF = W_F4_PT * NTHR * 4;          // padded likewise
     static constexpr size_t LDS_BYTES = size_t(2) * (IN_BUF + W_BUF) * sizeof(float);
     static_assert(CO_TILE == CONV_CO_TILE, "weight packing assumes 64-channel tiles");
     static_assert(PIX % TW == 0, "tile must be whole rows");
@@ -77,7 +78,7 @@ struct ConvGeom {
 };
 
 template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC>
-__global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvParams p) {
     using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const in_lds = smem;                    // [2][IN_BUF]
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvParam
         const int yy = e / G::IW, xx = e % G::IW;
         const int gy = oy0 * STRIDE - G::PAD + yy;
         const int gx = ox0 * STRIDE - G::PAD + xx;
-        const bool v = (e < G::CHS) && gy >= 0 && gy < p.Hc && gx >= 0 && gx < p.Wc;
+        const bool v = (e < G::IH * G::IW) && gy >= 0 && gy < p.Hc && gx >= 0 && gx < p.Wc;
         goff[i] = v ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : 0;
         vmask |= (v ? 1u : 0u) << i;
     }
@@ -147,63 +148,58 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvParam
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
     float rin[G::EPT];
-    float4 rw[G::W_F4_PT];
+    float rw[G::W_F4_PT * 4];   // scalars, not a float4 array: hipcc keeps a float4[] staging array in scratch
     float gsc = 1.0f, gsh = 0.0f;
     bool cval = false;
+
+    // All staging loads are UNCONDITIONAL at clamped, always-valid addresses and masked afterwards:
+    // a per-element "load or zero" select makes hipcc branch around every load and wait vmcnt(0)
+    // inside each branch, which serialises the whole prefetch (cdna_hip_programming.md, .s-level trap c).
+    const int prologue = (p.gn_scale == nullptr) ? 0 : (p.gn_silu ? 2 : 1);   // wave-uniform
 
     auto load_chunk = [&](int chunk) {
         const int c = chunk * CIC + sci;
         cval = c < Cin;
-        const float* src = p.in0;
-        if (cval) {
-            src = (c < p.c0) ? p.in0 + ((size_t)b * p.c0 + c) * HWin
-                             : p.in1 + ((size_t)b * p.c1 + (c - p.c0)) * HWin;
-        }
+        const int cc = min(c, Cin - 1);
+        const float* src = (cc < p.c0) ? p.in0 + ((size_t)b * p.c0 + cc) * HWin
+                                       : p.in1 + ((size_t)b * p.c1 + (cc - p.c0)) * HWin;
 #pragma unroll
-        for (int i = 0; i < G::EPT; ++i) {
-            const bool v = cval && ((vmask >> i) & 1u);
-            rin[i] = v ? src[goff[i]] : 0.0f;
-        }
-        if (p.gn_scale != nullptr) {
-            gsc = cval ? p.gn_scale[(size_t)b * Cin + c] : 1.0f;
-            gsh = cval ? p.gn_shift[(size_t)b * Cin + c] : 0.0f;
+        for (int i = 0; i < G::EPT; ++i) rin[i] = src[goff[i]];
+        if (prologue) {
+            gsc = p.gn_scale[(size_t)b * Cin + cc];
+            gsh = p.gn_shift[(size_t)b * Cin + cc];
         }
         const float* wsrc = p.w + (size_t)chunk * CIC * G::KK * p.cout_pad + co0;
 #pragma unroll
         for (int i = 0; i < G::W_F4_PT; ++i) {
-            const int f = tid + i * G::NTHR;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < G::W_F4) {
-                const int rr = f / (G::CO_TILE / 4), c4 = f % (G::CO_TILE / 4);
-                v = *reinterpret_cast<const float4*>(wsrc + (size_t)rr * p.cout_pad + c4 * 4);
-            }
-            rw[i] = v;
+            const int f = min(tid + i * G::NTHR, G::W_F4 - 1);
+            const int rr = f / (G::CO_TILE / 4), c4 = f % (G::CO_TILE / 4);
+            const float4 t = *reinterpret_cast<const float4*>(wsrc + (size_t)rr * p.cout_pad + c4 * 4);
+            rw[4 * i + 0] = t.x; rw[4 * i + 1] = t.y; rw[4 * i + 2] = t.z; rw[4 * i + 3] = t.w;
         }
     };
 
     auto store_chunk = [&](int buf) {
         float* dst = in_lds + buf * G::IN_BUF + sci * G::CHS + sl;
-        const bool gn = p.gn_scale != nullptr;
-        const bool act = p.gn_silu != 0;
+        const unsigned m = cval ? vmask : 0u;       // padding / missing channels stay zero AFTER the prologue
+        float v[G::EPT];
+        if (prologue == 2) {
 #pragma unroll
-        for (int i = 0; i < G::EPT; ++i) {
-            const int e = sl + i * G::TPC;
-            if (e < G::CHS) {
-                float v = rin[i];
-                if (gn) {
-                    v = v * gsc + gsh;
-                    if (act) v = silu_f(v);
-                    if (!(cval && ((vmask >> i) & 1u))) v = 0.0f;   // padding stays zero after the prologue
-                }
-                dst[i * G::TPC] = v;
-            }
-        }
-        float* wdst = w_lds + buf * G::W_BUF;
+            for (int i = 0; i < G::EPT; ++i) v[i] = silu_f(rin[i] * gsc + gsh);
+        } else if (prologue == 1) {
 #pragma unroll
-        for (int i = 0; i < G::W_F4_PT; ++i) {
-            const int f = tid + i * G::NTHR;
-            if (f < G::W_F4) *reinterpret_cast<float4*>(wdst + f * 4) = rw[i];
+            for (int i = 0; i < G::EPT; ++i) v[i] = rin[i] * gsc + gsh;
+        } else {
+#pragma unroll
+            for (int i = 0; i < G::EPT; ++i) v[i] = rin[i];
         }
+#pragma unroll
+        for (int i = 0; i < G::EPT; ++i) dst[i * G::TPC] = ((m >> i) & 1u) ? v[i] : 0.0f;
+        float* wdst = w_lds + buf * G::W_BUF + tid * 4;
+#pragma unroll
+        for (int i = 0; i < G::W_F4_PT; ++i)
+            *reinterpret_cast<float4*>(wdst + i * G::NTHR * 4) =
+                make_float4(rw[4 * i + 0], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]);
     };
 
     auto compute_chunk = [&](int buf) {
@@ -245,27 +241,56 @@ __global__ void __launch_bounds__(64 * WM * WN) conv_mfma_kernel(const ConvParam
         __syncthreads();
     }
 
-    // ---- epilogue: bias + per-sample channel bias (time embedding) + residual, NCHW store
+    // ---- epilogue: bias + per-sample channel bias (time embedding) + residual, NCHW store.
+    // Loads use clamped indices and are unconditional; only the stores are predicated.
     const size_t HWout = (size_t)p.Hout * p.Wout;
+    float cbias[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            cbias[m][r] = 0.0f;
+        }
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cbias[m][r] += p.bias[min(co0 + wm * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1)];
+    }
+    if (p.chan_bias) {
+        const float* cb = p.chan_bias + (size_t)b * p.chan_bias_stride;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                cbias[m][r] += cb[min(co0 + wm * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1)];
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int pix = wn * NT * 32 + n * 32 + l31;
         const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
         const bool pv = oy < p.Hout && ox < p.Wout;
+        const size_t pix_off = (size_t)min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = 0.0f;
+            if (p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = min(co0 + wm * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1);
+                    res[r] = p.residual[((size_t)b * p.Cout + co) * HWout + pix_off];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pv && co < p.Cout) {
-                    const size_t idx = ((size_t)b * p.Cout + co) * HWout + (size_t)oy * p.Wout + ox;
-                    float v = acc[m][n][r];
-                    if (p.bias) v += p.bias[co];
-                    if (p.chan_bias) v += p.chan_bias[(size_t)b * p.chan_bias_stride + co];
-                    if (p.residual) v += p.residual[idx];
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    p.out[idx] = v;
-                }
+                float v = acc[m][n][r] + cbias[m][r] + res[r];
+                if (p.relu) v = fmaxf(v, 0.0f);
+                if (pv && co < p.Cout) p.out[((size_t)b * p.Cout + co) * HWout + pix_off] = v;
             }
         }
     }
@@ -320,6 +345,7 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 
 // Tile configurations.  id -> (KS, STRIDE, MT, NT, WM, WN, TW):
 //   3x3 s1:  1: 2,2,1,4,TW64   2: 2,2,1,4,TW32   3: 2,2,1,4,TW16   4: 1,1,2,2,TW8   5: 2,1,1,4,TW16 (PIX128)
+//            6: 2,1,1,4,TW64   7: 2,1,1,4,TW32 (PIX128)   8: 1,2,2,4,TW32   9: 1,2,2,4,TW16 (8 waves, PIX256)
 //   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
 //   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
 int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
@@ -357,20 +383,24 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
         // 1x1: the image is a flat row of H*W pixels
         p.Hin = 1; p.Win = a.Hin * a.Win; p.Hc = 1; p.Wc = p.Win; p.Hout = 1; p.Wout = p.Win; p.ups = 0;
         SISIC_REQUIRE(!a.upsample, "conv2d: 1x1 with upsample");
-        if (cfg == 0) cfg = (p.Wout <= 64) ? 22 : 21;
+        if (cfg == 0) cfg = (p.Wout <= 64) ? 22 : 23;       // measured (tools/conv_bench.py, B=64)
         switch (cfg) {
             case 21: return launch_cfg<1, 1, 2, 2, 1, 4, 256, 16>(ctx, p, s);
             case 22: return launch_cfg<1, 1, 1, 1, 2, 2, 64, 16>(ctx, p, s);
             case 23: return launch_cfg<1, 1, 2, 1, 1, 4, 128, 16>(ctx, p, s);
         }
     } else if (a.stride == 1) {
-        if (cfg == 0) cfg = p.Wout >= 48 ? 1 : (p.Wout >= 24 ? 2 : (p.Wout >= 12 ? 3 : 4));
+        if (cfg == 0) cfg = p.Wout >= 24 ? 8 : (p.Wout >= 12 ? 9 : 4);   // measured (tools/conv_bench.py, B=64)
         switch (cfg) {
             case 1: return launch_cfg<3, 1, 2, 2, 1, 4, 64, 8>(ctx, p, s);
             case 2: return launch_cfg<3, 1, 2, 2, 1, 4, 32, 8>(ctx, p, s);
             case 3: return launch_cfg<3, 1, 2, 2, 1, 4, 16, 8>(ctx, p, s);
             case 4: return launch_cfg<3, 1, 1, 1, 2, 2, 8, 8>(ctx, p, s);
             case 5: return launch_cfg<3, 1, 2, 1, 1, 4, 16, 8>(ctx, p, s);
+            case 6: return launch_cfg<3, 1, 2, 1, 1, 4, 64, 8>(ctx, p, s);
+            case 7: return launch_cfg<3, 1, 2, 1, 1, 4, 32, 8>(ctx, p, s);
+            case 8: return launch_cfg<3, 1, 1, 2, 2, 4, 32, 8>(ctx, p, s);
+            case 9: return launch_cfg<3, 1, 1, 2, 2, 4, 16, 8>(ctx, p, s);
         }
     } else {
         if (cfg == 0) cfg = p.Wout >= 24 ? 11 : (p.Wout >= 12 ? 12 : 13);

@@ -66,7 +66,8 @@ def _run_conv(x, w, cfg, **kw):
 
 # (cfg, H, W) -- natural shapes for each tile configuration plus ragged ones that exercise the masks
 CONV3_S1 = [(1, 64, 64), (1, 12, 70), (2, 32, 32), (2, 20, 40), (3, 16, 16), (3, 24, 24), (4, 8, 8), (4, 9, 5),
-            (5, 16, 16), (0, 64, 64), (0, 8, 8)]
+            (5, 16, 16), (6, 64, 64), (6, 10, 70), (7, 32, 32), (7, 9, 40), (8, 32, 32), (8, 20, 40), (9, 16, 16),
+            (9, 24, 20), (0, 64, 64), (0, 8, 8)]
 
 
 @pytest.mark.parametrize("cfg,H,W", CONV3_S1)
@@ -93,7 +94,7 @@ def test_conv3x3_no_bias_and_identity_weight():
     w = torch.zeros(C, C, 3, 3)
     for c in range(C):
         w[c, c, 1, 1] = 1.0
-    for cfg in (1, 2, 3, 4, 5):
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         got = _run_conv(x, w, cfg).cpu()
         assert torch.equal(got, x), f"identity conv cfg{cfg} is not exact"
     # shifted identity: out[c] = in[(c+1) % C] moved one pixel right
@@ -105,7 +106,8 @@ def test_conv3x3_no_bias_and_identity_weight():
         assert torch.equal(_run_conv(x, w2, cfg).cpu(), want)
 
 
-@pytest.mark.parametrize("cfg,H,W", [(1, 64, 64), (2, 32, 32), (3, 16, 16), (4, 8, 8), (2, 20, 24)])
+@pytest.mark.parametrize("cfg,H,W", [(1, 64, 64), (2, 32, 32), (3, 16, 16), (4, 8, 8), (2, 20, 24), (5, 16, 16),
+                                     (6, 64, 64), (7, 32, 32), (8, 32, 32), (9, 16, 16)])
 def test_conv3x3_fused_everything(cfg, H, W):
     """two sources whose seam falls inside a channel chunk + GN/SiLU prologue + time bias + residual."""
     B, c0, c1, cout = 2, 20, 12, 64
