@@ -160,6 +160,32 @@ int sisic_sample(sisic_unet*, float* x, int B, int H, int W, int T, const int64_
                  const float* coef, float clip, const float* noise, float* traj, uint8_t* out_u8,
                  const volatile int* cancel, int* steps_done, void* stream);
 
+/* ---- ResNet18 classifier (xai/XAI.py:357-471, forward only) ---------------------------- */
+/* torchvision resnet18 with fc -> num_classes, eval mode (BatchNorm folded at load).  The state dict
+ * uses the reference's key names, prefixed "model." (XAI.py:389), float tensors only: conv/fc weights
+ * and biases, BatchNorm weight/bias/running_mean/running_var (num_batches_tracked is not a float tensor
+ * and is not passed).                                                                         */
+int sisic_resnet_create(sisic_ctx*, int num_classes, sisic_resnet** out);
+int sisic_resnet_destroy(sisic_resnet*);
+int sisic_resnet_num_tensors(const sisic_resnet*);
+const char* sisic_resnet_tensor_name(const sisic_resnet*, int index);
+int sisic_resnet_load(sisic_resnet*, int n, const char* const* names, const float* const* host_ptrs,
+                      const int64_t* numels);
+/* logits[B,num_classes] = classifier.forward(x).  preprocess=1: x is dev [B,3,H,W] in [-1,1] (the
+ * sampler's latents) and goes through preprocess_for_classifier (XAI.py:399-431): clamp((x+1)/2,0,1),
+ * bilinear resize to 224x224 (H,W <= 224), ImageNet normalisation.  preprocess=0: x is already the
+ * normalised network input [B,3,H,W].                                                         */
+int sisic_resnet_forward(sisic_resnet*, const float* x, float* logits, int B, int H, int W, int preprocess,
+                         void* stream);
+/* get_confidence / get_per_class_score (XAI.py:443-471): prob[b] = softmax(logits[b])[target],
+ * logscore[b] = log(prob[b] + 1e-8); either output may be NULL.                               */
+int sisic_class_scores(sisic_ctx*, const float* logits, int B, int n_classes, int target, float* prob,
+                       float* logscore, void* stream);
+/* The masked copies of compute_shap_approximation (XAI.py:1147-1161): out[s,c,y,x] = image[c,y,x] where
+ * masks[s, y/patch, x/patch] != 0, else 0.  image: dev [C,H,W]; masks: dev uint8 [S,H/patch,W/patch].  */
+int sisic_mask_patches(sisic_ctx*, const float* image, const uint8_t* masks, float* out, int S, int C, int H, int W,
+                       int patch, void* stream);
+
 /* ---- instrumentation (bench.py roofline leg) -------------------------------------- */
 /* When enabled, every conv launch is bracketed by HIP events on its own stream and
  * accumulated per class; reading synchronises the stream.                           */

@@ -76,6 +76,17 @@ SIGNATURES = {
     "sisic_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int64_p, c_float_p,
                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.c_void_p]),
+    "sisic_resnet_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "sisic_resnet_destroy": (C.c_int, [C.c_void_p]),
+    "sisic_resnet_num_tensors": (C.c_int, [C.c_void_p]),
+    "sisic_resnet_tensor_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "sisic_resnet_load": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_int64_p]),
+    "sisic_resnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
+    "sisic_class_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]),
+    "sisic_mask_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p]),
     "sisic_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "sisic_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_int64_p, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]),

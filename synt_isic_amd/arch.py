@@ -157,3 +157,29 @@ def normalize_state_dict_keys(sd: Dict[str, object]) -> Dict[str, object]:
             k = ".".join(parts)
         out[k] = v
     return out
+
+
+def resnet18_param_spec(num_classes: int = 7) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Float tensors of the reference classifier's state dict (xai/XAI.py:385-397: torchvision resnet18
+    held as ``self.model`` => keys prefixed ``model.``, fc replaced by Linear(512, num_classes))."""
+    spec: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv_bn(conv, bn, cout, cin, k):
+        spec[f"model.{conv}.weight"] = (cout, cin, k, k)
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            spec[f"model.{bn}.{s}"] = (cout,)
+
+    conv_bn("conv1", "bn1", 64, 3, 7)
+    in_ch = 64
+    for l, width in enumerate((64, 128, 256, 512)):
+        for j in range(2):
+            stride = 2 if (l > 0 and j == 0) else 1
+            base = f"layer{l + 1}.{j}"
+            conv_bn(f"{base}.conv1", f"{base}.bn1", width, in_ch, 3)
+            conv_bn(f"{base}.conv2", f"{base}.bn2", width, width, 3)
+            if stride != 1 or in_ch != width:
+                conv_bn(f"{base}.downsample.0", f"{base}.downsample.1", width, in_ch, 1)
+            in_ch = width
+    spec["model.fc.weight"] = (num_classes, 512)
+    spec["model.fc.bias"] = (num_classes,)
+    return spec

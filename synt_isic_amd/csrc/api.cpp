@@ -99,7 +99,7 @@ int sisic_destroy(sisic_ctx* ctx) {
 }
 
 int64_t sisic_conv_packed_numel(int Cout, int Cin, int ksize) {
-    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return -1;
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3 && ksize != 7)) return -1;
     return (int64_t)conv_cin_pad(Cin, ksize) * ksize * ksize * conv_cout_pad(Cout);
 }
 

@@ -103,5 +103,14 @@ int launch_linear_t(sisic_ctx*, const float* x, int B, int K, const float* wt, c
                     float* out, hipStream_t s);
 int launch_transpose2d(sisic_ctx*, const float* in, int rows, int cols, float* out, int out_ld, int out_col0,
                        hipStream_t s);
+// classifier.hip
+int launch_preprocess(sisic_ctx*, const float* x, float* out, int B, int H, int W, int OH, int OW, hipStream_t s);
+int launch_maxpool(sisic_ctx*, const float* x, float* out, int B, int C, int H, int W, hipStream_t s);
+int launch_avgpool_fc(sisic_ctx*, const float* x, const float* w, const float* bias, float* out, int B, int C, int HW,
+                      int n_out, hipStream_t s);
+int launch_class_scores(sisic_ctx*, const float* logits, int B, int n, int target, float* prob, float* logscore,
+                        hipStream_t s);
+int launch_mask_patches(sisic_ctx*, const float* image, const uint8_t* masks, float* out, int S, int C, int H, int W,
+                        int patch, hipStream_t s);
 
 }  // namespace sisic

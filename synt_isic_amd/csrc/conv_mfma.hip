@@ -334,7 +334,7 @@ static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
 }
 
 int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float* packed, hipStream_t s) {
-    SISIC_REQUIRE(k == 1 || k == 3, "conv_pack: ksize %d unsupported", k);
+    SISIC_REQUIRE(k == 1 || k == 3 || k == 7, "conv_pack: ksize %d unsupported", k);
     const int cin_pad = conv_cin_pad(Cin, k), cout_pad = conv_cout_pad(Cout);
     const size_t total = (size_t)cin_pad * k * k * cout_pad;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
@@ -348,12 +348,14 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 //            6: 2,1,1,4,TW64   7: 2,1,1,4,TW32 (PIX128)   8: 1,2,2,4,TW32   9: 1,2,2,4,TW16 (8 waves, PIX256)
 //   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
 //   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
+//   1x1 s2: 31: 2,1,1,4,TW32  32: 2,1,1,4,TW16  33: 1,1,2,2,TW8      7x7 s2: 41: 2,1,1,4,TW32 (CIC 4)
 int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
     SISIC_REQUIRE(a.in0 && a.w_packed && a.out, "conv2d: null tensor");
     SISIC_REQUIRE(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.c0 > 0 && a.c1 >= 0 && a.Cout > 0, "conv2d: bad shape");
     SISIC_REQUIRE((a.c1 == 0) == (a.in1 == nullptr), "conv2d: in1/c1 mismatch");
-    SISIC_REQUIRE(a.ksize == 1 || a.ksize == 3, "conv2d: ksize %d unsupported", a.ksize);
-    SISIC_REQUIRE(a.stride == 1 || (a.stride == 2 && a.ksize == 3), "conv2d: stride %d unsupported", a.stride);
+    SISIC_REQUIRE(a.ksize == 1 || a.ksize == 3 || a.ksize == 7, "conv2d: ksize %d unsupported", a.ksize);
+    SISIC_REQUIRE(a.stride == 1 || a.stride == 2, "conv2d: stride %d unsupported", a.stride);
+    SISIC_REQUIRE(a.ksize != 7 || a.stride == 2, "conv2d: 7x7 is built for stride 2 only (the ResNet stem)");
     SISIC_REQUIRE(!(a.upsample && a.stride != 1), "conv2d: upsample with stride");
     SISIC_REQUIRE((a.gn_scale == nullptr) == (a.gn_shift == nullptr), "conv2d: gn_scale/gn_shift mismatch");
 
@@ -379,7 +381,17 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
     ProfileScope prof(ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops);
 
     int cfg = a.tile_cfg;
-    if (a.ksize == 1) {
+    if (a.ksize == 7) {
+        if (cfg == 0) cfg = 41;
+        if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 4>(ctx, p, s);
+    } else if (a.ksize == 1 && a.stride == 2) {
+        if (cfg == 0) cfg = p.Wout >= 24 ? 31 : (p.Wout >= 12 ? 32 : 33);
+        switch (cfg) {
+            case 31: return launch_cfg<1, 2, 2, 1, 1, 4, 32, 16>(ctx, p, s);
+            case 32: return launch_cfg<1, 2, 2, 1, 1, 4, 16, 16>(ctx, p, s);
+            case 33: return launch_cfg<1, 2, 1, 1, 2, 2, 8, 16>(ctx, p, s);
+        }
+    } else if (a.ksize == 1) {
         // 1x1: the image is a flat row of H*W pixels
         p.Hin = 1; p.Win = a.Hin * a.Win; p.Hc = 1; p.Wc = p.Win; p.Hout = 1; p.Wout = p.Win; p.ups = 0;
         SISIC_REQUIRE(!a.upsample, "conv2d: 1x1 with upsample");

@@ -1,0 +1,310 @@
+// resnet.cpp -- forward pass of the ResNet18 classifier used by the reference's explainability passes
+// (xai/XAI.py:357-471: torchvision resnet18 with fc -> num_classes, eval mode).
+//
+// BatchNorm (eval) is folded into the preceding convolution at load time, in float64:
+//     w' = w * gamma / sqrt(var + eps),   b' = beta - mean * gamma / sqrt(var + eps)
+// so every conv+BN(+ReLU)(+identity) is ONE launch of conv_mfma_kernel with its bias / residual / ReLU
+// epilogue.  The pre-processing of XAI.py:399-431 is one fused kernel (classifier.hip).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "common.h"
+
+using namespace sisic;
+
+namespace {
+
+struct FoldedConv {
+    int cout = 0, cin = 0, k = 0, stride = 1;
+    int w_idx = -1;
+    int bn_w = -1, bn_b = -1, bn_m = -1, bn_v = -1;
+    float* packed = nullptr;
+    float* bias = nullptr;
+};
+
+struct Block {
+    FoldedConv conv1, conv2, down;   // down.k == 0 when the shortcut is the identity
+};
+
+struct RBlock {
+    float* p;
+    size_t bytes;
+    bool free_;
+};
+
+}  // namespace
+
+struct sisic_resnet {
+    sisic_ctx* ctx = nullptr;
+    int num_classes = 0;
+    std::vector<std::string> names;
+    std::vector<int64_t> numels;
+    std::map<std::string, int> index;
+    std::vector<std::vector<float>> host;   // host copies (folding happens on the host)
+    FoldedConv stem;
+    std::vector<Block> blocks;
+    int fc_w = -1, fc_b = -1;
+    float* d_fc_w = nullptr;
+    float* d_fc_b = nullptr;
+    std::vector<float*> owned;
+    std::vector<RBlock> pool;
+    bool loaded = false;
+
+    int add(const std::string& n, int64_t numel) {
+        index[n] = (int)names.size();
+        names.push_back(n);
+        numels.push_back(numel);
+        return (int)names.size() - 1;
+    }
+};
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f;   // torchvision BatchNorm2d default
+
+void add_conv_bn(sisic_resnet* r, FoldedConv& c, const std::string& conv, const std::string& bn, int cout, int cin, int k,
+                 int stride) {
+    c.cout = cout; c.cin = cin; c.k = k; c.stride = stride;
+    c.w_idx = r->add(conv + ".weight", (int64_t)cout * cin * k * k);
+    c.bn_w = r->add(bn + ".weight", cout);
+    c.bn_b = r->add(bn + ".bias", cout);
+    c.bn_m = r->add(bn + ".running_mean", cout);
+    c.bn_v = r->add(bn + ".running_var", cout);
+}
+
+void describe(sisic_resnet* r) {
+    const std::string pre = "model.";           // XAI.py:389: self.model = models.resnet18(...)
+    add_conv_bn(r, r->stem, pre + "conv1", pre + "bn1", 64, 3, 7, 2);
+    const int widths[4] = {64, 128, 256, 512};
+    int in_ch = 64;
+    for (int l = 0; l < 4; ++l) {
+        for (int j = 0; j < 2; ++j) {
+            Block b;
+            const int stride = (l > 0 && j == 0) ? 2 : 1;
+            const std::string base = pre + "layer" + std::to_string(l + 1) + "." + std::to_string(j);
+            add_conv_bn(r, b.conv1, base + ".conv1", base + ".bn1", widths[l], in_ch, 3, stride);
+            add_conv_bn(r, b.conv2, base + ".conv2", base + ".bn2", widths[l], widths[l], 3, 1);
+            if (stride != 1 || in_ch != widths[l])
+                add_conv_bn(r, b.down, base + ".downsample.0", base + ".downsample.1", widths[l], in_ch, 1, stride);
+            r->blocks.push_back(b);
+            in_ch = widths[l];
+        }
+    }
+    r->fc_w = r->add(pre + "fc.weight", (int64_t)r->num_classes * 512);
+    r->fc_b = r->add(pre + "fc.bias", r->num_classes);
+}
+
+int dev_alloc(sisic_resnet* r, size_t floats, float** out) {
+    void* p = nullptr;
+    SISIC_HIP(hipMalloc(&p, std::max<size_t>(floats, 4) * sizeof(float)));
+    r->owned.push_back(static_cast<float*>(p));
+    *out = static_cast<float*>(p);
+    return SISIC_OK;
+}
+
+int fold(sisic_resnet* r, FoldedConv& c) {
+    if (c.k == 0) return SISIC_OK;
+    const std::vector<float>& w = r->host[c.w_idx];
+    const std::vector<float>& g = r->host[c.bn_w];
+    const std::vector<float>& be = r->host[c.bn_b];
+    const std::vector<float>& m = r->host[c.bn_m];
+    const std::vector<float>& v = r->host[c.bn_v];
+    const size_t per = (size_t)c.cin * c.k * c.k;
+    std::vector<float> wf(w.size()), bf(c.cout);
+    for (int co = 0; co < c.cout; ++co) {
+        const double sc = (double)g[co] / std::sqrt((double)v[co] + (double)BN_EPS);
+        for (size_t i = 0; i < per; ++i) wf[co * per + i] = (float)((double)w[co * per + i] * sc);
+        bf[co] = (float)((double)be[co] - (double)m[co] * sc);
+    }
+    float* raw = nullptr;
+    SISIC_TRY(dev_alloc(r, wf.size(), &raw));
+    SISIC_HIP(hipMemcpy(raw, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
+    SISIC_TRY(dev_alloc(r, (size_t)sisic_conv_packed_numel(c.cout, c.cin, c.k), &c.packed));
+    SISIC_TRY(launch_conv_pack(r->ctx, raw, c.cout, c.cin, c.k, c.packed, nullptr));
+    SISIC_TRY(dev_alloc(r, c.cout, &c.bias));
+    SISIC_HIP(hipMemcpy(c.bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+    return SISIC_OK;
+}
+
+int pool_get(sisic_resnet* r, size_t floats, float** out) {
+    const size_t bytes = floats * sizeof(float);
+    for (auto& b : r->pool)
+        if (b.free_ && b.bytes == bytes) { b.free_ = false; *out = b.p; return SISIC_OK; }
+    void* p = nullptr;
+    SISIC_HIP(hipMalloc(&p, bytes));
+    r->pool.push_back({static_cast<float*>(p), bytes, false});
+    *out = static_cast<float*>(p);
+    return SISIC_OK;
+}
+
+void pool_put(sisic_resnet* r, float* p) {
+    for (auto& b : r->pool)
+        if (b.p == p) { b.free_ = true; return; }
+}
+
+int run_conv(sisic_resnet* r, const FoldedConv& c, const float* in, int B, int H, int W, const float* residual, bool relu,
+             float* out, hipStream_t s) {
+    sisic_conv_args a{};
+    a.in0 = in; a.c0 = c.cin; a.B = B; a.Hin = H; a.Win = W;
+    a.ksize = c.k; a.stride = c.stride;
+    a.w_packed = c.packed; a.bias = c.bias; a.Cout = c.cout;
+    a.residual = residual; a.relu = relu ? 1 : 0; a.out = out;
+    return launch_conv2d(r->ctx, a, s);
+}
+
+inline int out_dim(int n, int k, int stride) { return (n + 2 * (k / 2) - k) / stride + 1; }
+
+}  // namespace
+
+extern "C" {
+
+int sisic_resnet_create(sisic_ctx* ctx, int num_classes, sisic_resnet** out) {
+    SISIC_REQUIRE(ctx && out && num_classes > 0 && num_classes <= 1000, "resnet_create: bad arguments");
+    auto* r = new sisic_resnet();
+    r->ctx = ctx;
+    r->num_classes = num_classes;
+    describe(r);
+    *out = r;
+    return SISIC_OK;
+}
+
+int sisic_resnet_destroy(sisic_resnet* r) {
+    if (!r) return SISIC_OK;
+    (void)hipDeviceSynchronize();
+    for (auto p : r->owned) (void)hipFree(p);
+    for (auto& b : r->pool) (void)hipFree(b.p);
+    delete r;
+    return SISIC_OK;
+}
+
+int sisic_resnet_num_tensors(const sisic_resnet* r) { return r ? (int)r->names.size() : 0; }
+
+const char* sisic_resnet_tensor_name(const sisic_resnet* r, int i) {
+    if (!r || i < 0 || i >= (int)r->names.size()) return nullptr;
+    return r->names[i].c_str();
+}
+
+int sisic_resnet_load(sisic_resnet* r, int n, const char* const* names, const float* const* host_ptrs,
+                      const int64_t* numels) {
+    SISIC_REQUIRE(r && names && host_ptrs && numels, "resnet_load: null argument");
+    SISIC_REQUIRE(n == (int)r->names.size(), "resnet_load: state dict has %d float tensors, expected %d", n, (int)r->names.size());
+    SISIC_HIP(hipSetDevice(r->ctx->device));
+    r->host.assign(r->names.size(), {});
+    std::vector<char> seen(r->names.size(), 0);
+    for (int i = 0; i < n; ++i) {
+        SISIC_REQUIRE(names[i] && host_ptrs[i], "resnet_load: entry %d is null", i);
+        auto it = r->index.find(names[i]);
+        SISIC_REQUIRE(it != r->index.end(), "resnet_load: unexpected key '%s'", names[i]);
+        const int idx = it->second;
+        SISIC_REQUIRE(!seen[idx], "resnet_load: duplicate key '%s'", names[i]);
+        SISIC_REQUIRE(numels[i] == r->numels[idx], "resnet_load: '%s' has %lld elements, expected %lld", names[i],
+                      (long long)numels[i], (long long)r->numels[idx]);
+        seen[idx] = 1;
+        r->host[idx].assign(host_ptrs[i], host_ptrs[i] + numels[i]);
+    }
+    (void)hipDeviceSynchronize();
+    for (auto p : r->owned) (void)hipFree(p);
+    r->owned.clear();
+    r->loaded = false;
+    SISIC_TRY(fold(r, r->stem));
+    for (auto& b : r->blocks) {
+        SISIC_TRY(fold(r, b.conv1));
+        SISIC_TRY(fold(r, b.conv2));
+        SISIC_TRY(fold(r, b.down));
+    }
+    SISIC_TRY(dev_alloc(r, r->host[r->fc_w].size(), &r->d_fc_w));
+    SISIC_TRY(dev_alloc(r, r->host[r->fc_b].size(), &r->d_fc_b));
+    SISIC_HIP(hipMemcpy(r->d_fc_w, r->host[r->fc_w].data(), r->host[r->fc_w].size() * sizeof(float), hipMemcpyHostToDevice));
+    SISIC_HIP(hipMemcpy(r->d_fc_b, r->host[r->fc_b].data(), r->host[r->fc_b].size() * sizeof(float), hipMemcpyHostToDevice));
+    SISIC_HIP(hipDeviceSynchronize());
+    r->loaded = true;
+    return SISIC_OK;
+}
+
+int sisic_resnet_forward(sisic_resnet* r, const float* x, float* logits, int B, int H, int W, int preprocess,
+                         void* stream) {
+    SISIC_REQUIRE(r && x && logits && B > 0 && H > 0 && W > 0, "resnet_forward: bad arguments");
+    if (!r->loaded) {
+        set_error("resnet_forward called before sisic_resnet_load");
+        return SISIC_ESTATE;
+    }
+    SISIC_HIP(hipSetDevice(r->ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<float*> live;
+    auto get = [&](size_t floats, float** p) {
+        const int rc = pool_get(r, floats, p);
+        if (rc == SISIC_OK) live.push_back(*p);
+        return rc;
+    };
+    auto put = [&](float* p) {
+        pool_put(r, p);
+        live.erase(std::remove(live.begin(), live.end(), p), live.end());
+    };
+    auto body = [&]() -> int {
+        const float* cur = x;
+        int h = H, w = W;
+        float* pre = nullptr;
+        if (preprocess) {
+            const int S = 224;                      // CLASSIFIER_IMAGE_SIZE, XAI.py
+            SISIC_TRY(get((size_t)B * 3 * S * S, &pre));
+            SISIC_TRY(launch_preprocess(r->ctx, x, pre, B, H, W, S, S, s));
+            cur = pre; h = S; w = S;
+        }
+        // stem: conv7x7 s2 (+BN) + ReLU, maxpool 3x3 s2
+        int oh = out_dim(h, 7, 2), ow = out_dim(w, 7, 2);
+        float* c1 = nullptr;
+        SISIC_TRY(get((size_t)B * 64 * oh * ow, &c1));
+        SISIC_TRY(run_conv(r, r->stem, cur, B, h, w, nullptr, true, c1, s));
+        if (pre) put(pre);
+        h = oh; w = ow;
+        oh = out_dim(h, 3, 2); ow = out_dim(w, 3, 2);
+        float* act = nullptr;
+        SISIC_TRY(get((size_t)B * 64 * oh * ow, &act));
+        SISIC_TRY(launch_maxpool(r->ctx, c1, act, B, 64, h, w, s));
+        put(c1);
+        h = oh; w = ow;
+        int ch = 64;
+        for (const Block& b : r->blocks) {
+            const int bh = out_dim(h, 3, b.conv1.stride), bw = out_dim(w, 3, b.conv1.stride);
+            float* t1 = nullptr;
+            SISIC_TRY(get((size_t)B * b.conv1.cout * bh * bw, &t1));
+            SISIC_TRY(run_conv(r, b.conv1, act, B, h, w, nullptr, true, t1, s));
+            const float* identity = act;
+            float* ds = nullptr;
+            if (b.down.k) {
+                SISIC_TRY(get((size_t)B * b.down.cout * bh * bw, &ds));
+                SISIC_TRY(run_conv(r, b.down, act, B, h, w, nullptr, false, ds, s));
+                identity = ds;
+            }
+            float* t2 = nullptr;
+            SISIC_TRY(get((size_t)B * b.conv2.cout * bh * bw, &t2));
+            SISIC_TRY(run_conv(r, b.conv2, t1, B, bh, bw, identity, true, t2, s));    // relu(bn2(conv2) + identity)
+            put(t1);
+            if (ds) put(ds);
+            put(act);
+            act = t2; h = bh; w = bw; ch = b.conv2.cout;
+        }
+        SISIC_TRY(launch_avgpool_fc(r->ctx, act, r->d_fc_w, r->d_fc_b, logits, B, ch, h * w, r->num_classes, s));
+        put(act);
+        return SISIC_OK;
+    };
+    const int rc = body();
+    for (float* p : live) pool_put(r, p);
+    return rc;
+}
+
+int sisic_class_scores(sisic_ctx* ctx, const float* logits, int B, int n_classes, int target, float* prob,
+                       float* logscore, void* stream) {
+    SISIC_REQUIRE(ctx, "class_scores: null context");
+    return launch_class_scores(ctx, logits, B, n_classes, target, prob, logscore, static_cast<hipStream_t>(stream));
+}
+
+int sisic_mask_patches(sisic_ctx* ctx, const float* image, const uint8_t* masks, float* out, int S, int C, int H, int W,
+                       int patch, void* stream) {
+    SISIC_REQUIRE(ctx, "mask_patches: null context");
+    return launch_mask_patches(ctx, image, masks, out, S, C, H, W, patch, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -61,3 +61,24 @@ def state_dict_sha256(sd: Dict[str, torch.Tensor]) -> str:
         h.update(name.encode())
         h.update(t.detach().cpu().contiguous().numpy().tobytes())
     return h.hexdigest()
+
+
+def synthetic_resnet18_state_dict(seed: int = 4321, num_classes: int = 7) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded random classifier (``IMAGENET1K_V1`` weights are a network download, XAI.py:389, unavailable
+    offline).  Conv/fc ~ U(+-sqrt(3/fan_in)) (unit-gain so activations stay O(1) through 18 layers),
+    BatchNorm weight 1+0.1N, bias 0.1N, running_mean 0.1N, running_var 1+0.2|N|."""
+    from .arch import resnet18_param_spec
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int(seed))
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in resnet18_param_spec(num_classes).items():
+        if len(shape) >= 2:
+            bound = math.sqrt(3.0 / math.prod(shape[1:]))
+            sd[name] = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * bound
+        elif name.endswith("running_var"):
+            sd[name] = 1.0 + 0.2 * torch.randn(shape, generator=g, dtype=torch.float32).abs()
+        elif name.endswith("running_mean") or name.endswith(".bias"):
+            sd[name] = 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+        else:
+            sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+    return sd

@@ -1,0 +1,147 @@
+"""Batched forward passes of the reference's explainability analyses (xai/XAI.py), on the HIP kernels.
+
+* ``compute_time_shap``            -- XAI.py:1179-1234 as coded: per-frame classifier scores, min-max
+                                     normalised.  The reference runs 2 batch-1 forwards per frame; here the N
+                                     frames are ONE [N,3,H,W] batch.
+* ``compute_shap_approximation``   -- XAI.py:1111-1177: 512 random 16x16-patch coalitions x classifier score.
+                                     The reference runs 513 batch-1 forwards per image; here the coalition
+                                     images are built on the GPU (``sisic_mask_patches``) and scored in batches.
+* ``time_shap_permutation``        -- README.md:171-207: Shapley values of the denoising STEPS with
+                                     v(S) = F(Dec(x_T; S)) (transitions applied only on the steps in S, the other
+                                     steps are skipped) and the unbiased permutation estimator.  The reference
+                                     documents this form but does not implement it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .classifier import HipMelanomaClassifier
+from .sampler import Sampler, draw_noise, run_sampling_loop
+
+SHAP_N_SAMPLES = 512          # xai/XAI.py SHAP_N_SAMPLES
+
+
+def _as_batch(trajectory) -> torch.Tensor:
+    if torch.is_tensor(trajectory):
+        t = trajectory
+        return t.reshape((-1,) + tuple(t.shape[-3:])) if t.dim() == 5 else t
+    return torch.cat([f if f.dim() == 4 else f.unsqueeze(0) for f in trajectory], dim=0)
+
+
+@torch.no_grad()
+def compute_time_shap(classifier: HipMelanomaClassifier, trajectory, timesteps: Sequence[float], target_class: int):
+    """(normalized_importance, raw_data) exactly as XAI.py:1179-1234 returns them."""
+    frames = _as_batch(trajectory)
+    if frames.shape[0] != len(timesteps):
+        raise ValueError(f"{frames.shape[0]} frames but {len(timesteps)} timesteps")
+    prob, logscore = classifier._scores(frames, target_class)
+    confidence_scores = logscore.cpu().numpy().astype(np.float64)
+    prob_scores = prob.cpu().numpy().astype(np.float64)
+    if len(confidence_scores) > 1 and (confidence_scores.max() - confidence_scores.min()) > 1e-6:
+        normalized = (confidence_scores - confidence_scores.min()) / (confidence_scores.max() - confidence_scores.min())
+    else:
+        normalized = np.ones_like(confidence_scores) / len(confidence_scores)
+    raw = {"confidence_scores": confidence_scores, "probability_scores": prob_scores, "timesteps": list(timesteps)}
+    return normalized, raw
+
+
+def draw_patch_masks(n_samples: int, nh: int, nw: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """The reference's per-sample ``torch.rand(nh, nw) > 0.5`` draws (XAI.py:1147), in order, as one bool tensor."""
+    return torch.stack([torch.rand(nh, nw, generator=generator) > 0.5 for _ in range(n_samples)])
+
+
+@torch.no_grad()
+def compute_shap_approximation(classifier: HipMelanomaClassifier, image: torch.Tensor, target_class: int,
+                               n_samples: int = SHAP_N_SAMPLES, patch_size: int = 16,
+                               patch_masks: Optional[torch.Tensor] = None, chunk: int = 256) -> torch.Tensor:
+    """Attribution map [1,3,H,W] of XAI.py:1111-1177 for ONE image [1,3,H,W] in [-1,1]."""
+    dev = classifier.device
+    image = image.to(dev, torch.float32).contiguous()
+    if image.dim() != 4 or image.shape[0] != 1:
+        raise ValueError("compute_shap_approximation takes one image [1,3,H,W]")
+    _, Cc, H, W = image.shape
+    nh, nw = H // patch_size, W // patch_size
+    if patch_masks is None:
+        patch_masks = draw_patch_masks(n_samples, nh, nw)          # global CPU RNG, like the reference
+    if tuple(patch_masks.shape) != (n_samples, nh, nw):
+        raise ValueError(f"patch_masks must be [{n_samples},{nh},{nw}]")
+    masks_u8 = patch_masks.to(torch.uint8).contiguous().to(dev)
+    lib = _lib.load()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    baseline = classifier.get_per_class_score(torch.zeros_like(image), target_class)       # [1]
+    scores = torch.empty(n_samples, dtype=torch.float32, device=dev)
+    for s0 in range(0, n_samples, chunk):
+        s1 = min(n_samples, s0 + chunk)
+        batch = torch.empty((s1 - s0, Cc, H, W), dtype=torch.float32, device=dev)
+        check(lib.sisic_mask_patches(ops.context(dev), image.data_ptr(), masks_u8[s0:s1].data_ptr(), batch.data_ptr(),
+                                     s1 - s0, Cc, H, W, patch_size, stream))
+        scores[s0:s1] = classifier.get_per_class_score(batch, target_class)
+    # attribution = (1/n) * sum_s (score_s - baseline) * mask_s  -- a [n] x [n,nh,nw] contraction of ~10^4 values
+    contrib = (scores - baseline).double().cpu()
+    grid = torch.einsum("s,sij->ij", contrib, patch_masks.double()) / n_samples
+    full = torch.zeros(H, W, dtype=torch.float64)
+    full[: nh * patch_size, : nw * patch_size] = grid.repeat_interleave(patch_size, 0).repeat_interleave(patch_size, 1)
+    return full.float().to(dev).expand(1, Cc, H, W).contiguous()
+
+
+@torch.no_grad()
+def coalition_value(sampler: Sampler, classifier: HipMelanomaClassifier, class_name: str, x_T: torch.Tensor,
+                    z: torch.Tensor, T: int, coalitions: Sequence[Sequence[int]], target_class: int) -> torch.Tensor:
+    """v(S) for every coalition S (step indices into the T-step grid): the mean over the batch of the target
+    logit after a denoising run that applies only the steps in S.  x_T [B,3,H,W], z [n_noise,B,3,H,W] on the
+    GPU; the same x_T / z_t serve every coalition, so v is a deterministic set function."""
+    model = sampler.models[class_name]
+    sched_full = sampler.create_scheduler(T)
+    ts_full = sched_full.timesteps.clone()
+    noise_index = {}
+    k = 0
+    for i, t in enumerate(ts_full.tolist()):
+        if t > 0:
+            noise_index[i] = k
+            k += 1
+    values = []
+    for S in coalitions:
+        steps = sorted(set(int(s) for s in S))
+        if steps:
+            sched = sampler.create_scheduler(T)
+            sched.timesteps = ts_full[steps]                       # descending t, standard coefficients per step
+            zi = [noise_index[i] for i in steps if i in noise_index]
+            zs = z[zi].contiguous() if zi else None
+            x0 = run_sampling_loop(model, sched, x_T, zs).latents
+        else:
+            x0 = x_T
+        logits = classifier.forward(x0)
+        values.append(logits[:, target_class].mean())
+    return torch.stack(values)
+
+
+@torch.no_grad()
+def time_shap_permutation(sampler: Sampler, classifier: HipMelanomaClassifier, class_name: str, seeds: Sequence[int],
+                          T: int, target_class: int, n_permutations: int = 4, size: Tuple[int, int] = (64, 64),
+                          generator: Optional[torch.Generator] = None) -> Dict[str, np.ndarray]:
+    """Permutation estimator of README.md:198-207: phi_t = mean_m [ v(Pref_pi_m(t) u {t}) - v(Pref_pi_m(t)) ].
+    Per permutation the T+1 nested prefixes give every marginal, so efficiency holds exactly:
+    sum_t phi_t = v({all steps}) - v({})."""
+    H, W = size
+    sched = sampler.create_scheduler(T)
+    n_noise = sum(1 for t in sched.timesteps if int(t) > 0)
+    x_T, z = draw_noise(seeds, n_noise, (3, H, W))
+    x_T, z = x_T.to(sampler.device), z.to(sampler.device)
+    phi = np.zeros(T, dtype=np.float64)
+    v_full = v_empty = None
+    for _ in range(n_permutations):
+        perm = torch.randperm(T, generator=generator).tolist()
+        coalitions = [perm[:k] for k in range(T + 1)]
+        v = coalition_value(sampler, classifier, class_name, x_T, z, T, coalitions, target_class).double().cpu().numpy()
+        for k, step in enumerate(perm):
+            phi[step] += v[k + 1] - v[k]
+        v_empty, v_full = v[0], v[T]
+    phi /= n_permutations
+    return {"phi": phi, "v_full": np.float64(v_full), "v_empty": np.float64(v_empty),
+            "timesteps": np.array([int(t) for t in sched.timesteps])}

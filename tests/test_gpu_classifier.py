@@ -1,0 +1,185 @@
+"""ResNet18 classifier forward, the as-coded Time-SHAP / patch-SHAP passes and the README-form
+permutation Time-SHAP, through the C ABI, against the CPU oracle (oracle/resnet18.py).
+
+Tolerance: logits max-abs <= 2e-4 * max(1, |ref|_inf) (18 fp32 conv layers, BatchNorm folded in float64);
+scores follow from the logits; everything integer / mask-related is exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+NV = 1          # target class id of "NV" (xai/XAI.py:196)
+
+
+def _close(got, ref, tol, what=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    bound = tol * max(1.0, ref.abs().max().item())
+    err = (got - ref).abs().max().item()
+    assert got.shape == ref.shape and err <= bound, f"{what}: err {err:.3e} > {bound:.3e} (shape {tuple(got.shape)})"
+
+
+@pytest.fixture(scope="module")
+def clf_sd():
+    from synt_isic_amd.weights import synthetic_resnet18_state_dict
+    return synthetic_resnet18_state_dict()
+
+
+@pytest.fixture(scope="module")
+def clf(clf_sd):
+    from synt_isic_amd.classifier import HipMelanomaClassifier
+    m = HipMelanomaClassifier(num_classes=7, pretrained=False)
+    sd = dict(clf_sd)
+    sd["model.bn1.num_batches_tracked"] = torch.tensor(0)       # integer buffers of a real checkpoint are ignored
+    m.load_state_dict(sd)
+    return m.to(DEV).eval()
+
+
+def _x(B, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, 3, H, W, generator=g) * 0.8          # some values leave [-1,1]: the clamp is exercised
+
+
+@pytest.mark.parametrize("cfg,H,W", [(0, 224, 224), (41, 64, 48), (41, 30, 70)])
+def test_conv7x7_stride2(cfg, H, W):
+    from synt_isic_amd import ops
+    x = _x(2, H, W, 1)
+    w = torch.randn(64, 3, 7, 7, generator=torch.Generator().manual_seed(2)) * 0.1
+    b = torch.randn(64, generator=torch.Generator().manual_seed(3))
+    got = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV)), 64, 7, bias=b.to(DEV), stride=2, relu=True, tile_cfg=cfg)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=3))
+    _close(got, ref, 2e-5, f"conv7x7 s2 {H}x{W}")
+
+
+@pytest.mark.parametrize("cfg,H,W,cin,cout", [(0, 56, 56, 64, 128), (31, 56, 56, 64, 128), (32, 28, 28, 128, 256),
+                                              (33, 14, 14, 256, 512), (31, 30, 50, 24, 70), (0, 14, 14, 256, 512)])
+def test_conv1x1_stride2(cfg, H, W, cin, cout):
+    from synt_isic_amd import ops
+    x = _x(2, H, W, 4)[:, :1].repeat(1, cin, 1, 1) * torch.randn(1, cin, 1, 1, generator=torch.Generator().manual_seed(5))
+    w = torch.randn(cout, cin, 1, 1, generator=torch.Generator().manual_seed(6)) * 0.1
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(7))
+    got = ops.conv2d(x.contiguous().to(DEV), ops.pack_conv_weight(w.to(DEV)), cout, 1, bias=b.to(DEV), stride=2, tile_cfg=cfg)
+    _close(got, F.conv2d(x.double(), w.double(), b.double(), stride=2), 2e-5, f"conv1x1 s2 {H}x{W}")
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 64, 64), (2, 128, 128), (1, 224, 224), (2, 96, 40)])
+def test_classifier_logits(clf, clf_sd, B, H, W):
+    from oracle import resnet18 as ores
+    x = _x(B, H, W, 10 + H)
+    ref = ores.classifier_forward(clf_sd, x)
+    got = clf(x)                                        # a CPU tensor is moved to the model's device (XAI.py:407-409)
+    assert got.shape == (B, 7) and got.device.type == "cuda"
+    _close(got, ref, 2e-4, f"logits {B}x{H}x{W}")
+
+
+def test_classifier_preprocessed_input_and_bounds(clf, clf_sd):
+    from oracle import resnet18 as ores
+    from synt_isic_amd._lib import SisicError
+    x = _x(2, 64, 64, 20)
+    pre = ores.preprocess_for_classifier(x)
+    _close(clf.forward(pre.to(DEV), preprocessed=True), ores.resnet18_features(clf_sd, pre), 2e-4, "preprocessed")
+    with pytest.raises(SisicError, match="down-scale"):
+        clf(torch.zeros(1, 3, 256, 256))
+
+
+def test_scores_and_module_surface(clf, clf_sd):
+    from oracle import resnet18 as ores
+    x = _x(4, 64, 64, 30)
+    p_ref, s_ref = ores.class_scores(clf_sd, x, NV)
+    _close(clf.get_confidence(x, NV), p_ref, 2e-4, "confidence")
+    _close(clf.get_per_class_score(x, NV), s_ref, 5e-4, "log score")
+    probs = clf.get_probabilities(x)
+    assert probs.shape == (4, 7)
+    torch.testing.assert_close(probs.sum(1).cpu(), torch.ones(4), rtol=0, atol=1e-5)      # XAI.py:543-555 self-check
+    assert torch.equal(clf.predict(x).cpu(), ores.classifier_forward(clf_sd, x).argmax(1))
+    assert sum(p.numel() for p in clf.parameters()) == 11_180_103
+    assert next(clf.parameters()).device.type == "cuda" and clf.training is False
+
+
+def test_time_shap_as_coded(clf, clf_sd):
+    """compute_time_shap (XAI.py:1179-1234): N frames of a trajectory -> min-max normalised log-scores."""
+    from oracle import resnet18 as ores
+    from synt_isic_amd import xai
+    g = torch.Generator().manual_seed(40)
+    frames = [torch.randn(1, 3, 64, 64, generator=g) * (1.0 - 0.08 * i) for i in range(10)]
+    timesteps = list(range(900, -1, -100))
+    imp_ref, raw_ref = ores.time_shap_as_coded(clf_sd, frames, timesteps, NV)
+    imp, raw = xai.compute_time_shap(clf, [f.to(DEV) for f in frames], timesteps, NV)
+    assert imp.shape == (10,) and raw["timesteps"] == timesteps
+    np.testing.assert_allclose(raw["confidence_scores"], raw_ref["confidence_scores"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(raw["probability_scores"], raw_ref["probability_scores"], rtol=0, atol=2e-4)
+    rng = raw_ref["confidence_scores"].max() - raw_ref["confidence_scores"].min()
+    np.testing.assert_allclose(imp, imp_ref, rtol=0, atol=2e-3 / max(rng, 1e-3) + 1e-6)
+    assert imp.min() == 0.0 and imp.max() == 1.0
+    # flat scores -> uniform importance (the reference's else-branch)
+    same = [frames[0].to(DEV)] * 4
+    imp2, _ = xai.compute_time_shap(clf, same, [3, 2, 1, 0], NV)
+    np.testing.assert_allclose(imp2, np.full(4, 0.25))
+    # a [T,B,3,H,W] trajectory tensor from the sampler is accepted too
+    imp3, _ = xai.compute_time_shap(clf, torch.stack([f.to(DEV) for f in frames]), timesteps, NV)
+    np.testing.assert_array_equal(imp3, imp)
+
+
+def test_patch_shap_matches_oracle(clf, clf_sd):
+    """compute_shap_approximation (XAI.py:1111-1177) with the same patch masks on both sides."""
+    from oracle import resnet18 as ores
+    from synt_isic_amd import xai
+    image = _x(1, 64, 64, 50)
+    masks = xai.draw_patch_masks(12, 4, 4, generator=torch.Generator().manual_seed(51))
+    ref = ores.shap_approximation(clf_sd, image, NV, n_samples=12, patch_size=16, patch_masks=masks)
+    got = xai.compute_shap_approximation(clf, image, NV, n_samples=12, patch_size=16, patch_masks=masks, chunk=5)
+    assert got.shape == (1, 3, 64, 64)
+    _close(got, ref, 1e-3, "patch SHAP attribution")
+    # masked copies are built exactly: kept pixels equal the image, dropped pixels are zero
+    import ctypes as C
+    from synt_isic_amd import _lib, ops
+    out = torch.empty((12, 3, 64, 64), device=DEV)
+    m8 = masks.to(torch.uint8).to(DEV)
+    img = image.to(DEV)
+    _lib.check(_lib.load().sisic_mask_patches(ops.context(img.device), img.data_ptr(), m8.data_ptr(), out.data_ptr(),
+                                              12, 3, 64, 64, 16, None))
+    for s in range(12):
+        full = ores.expand_patch_mask(masks[s], 64, 64, 16)
+        want = image[0].clone()
+        want[:, ~full] = 0
+        assert torch.equal(out[s].cpu(), want)
+    # the default path draws its masks from the global CPU RNG like the reference (XAI.py:1147)
+    torch.manual_seed(7)
+    a = xai.compute_shap_approximation(clf, image, NV, n_samples=8)
+    torch.manual_seed(7)
+    b = xai.compute_shap_approximation(clf, image, NV, n_samples=8)
+    assert torch.equal(a, b)
+
+
+def test_permutation_time_shap_properties(clf, clf_sd, synthetic_sd):
+    """README.md:171-207 form: efficiency axiom (exact by telescoping), determinism, and v(S) against the oracle."""
+    from oracle import ddpm as oddpm, resnet18 as ores, sampler as osampler, unet as ounet
+    from synt_isic_amd import xai
+    from synt_isic_amd.sampler import Sampler, draw_noise
+    s = Sampler(DEV)
+    s.add_model("NV", synthetic_sd)
+    T = 6
+    r1 = xai.time_shap_permutation(s, clf, "NV", [0, 1], T, NV, n_permutations=2, size=(32, 32),
+                                   generator=torch.Generator().manual_seed(1))
+    r2 = xai.time_shap_permutation(s, clf, "NV", [0, 1], T, NV, n_permutations=2, size=(32, 32),
+                                   generator=torch.Generator().manual_seed(1))
+    assert r1["phi"].shape == (T,) and np.array_equal(r1["phi"], r2["phi"])
+    assert abs(r1["phi"].sum() - (r1["v_full"] - r1["v_empty"])) < 1e-9
+    # v(S) for S = {steps 0, 2, 5} vs the oracle: skip the other steps, standard coefficients on the kept ones
+    x_T, z = draw_noise([0, 1], T - 1, (3, 32, 32))
+    v = xai.coalition_value(s, clf, "NV", x_T.to(DEV), z.to(DEV), T, [[0, 2, 5], [], list(range(T))], NV)
+    sched = oddpm.DDPMSchedulerOracle(); sched.set_timesteps(T)
+    ts = [int(t) for t in sched.timesteps]
+    x = x_T.clone()
+    with torch.no_grad():
+        for i in (0, 2, 5):
+            eps = ounet.unet_forward(synthetic_sd, x, ts[i])
+            x = sched.step(eps, ts[i], x, noise=z[i] if ts[i] > 0 else None)
+    v_ref = ores.classifier_forward(clf_sd, x)[:, NV].mean().item()
+    assert abs(v[0].item() - v_ref) <= 2e-3 * max(1.0, abs(v_ref))
+    v_empty_ref = ores.classifier_forward(clf_sd, x_T)[:, NV].mean().item()
+    assert abs(v[1].item() - v_empty_ref) <= 2e-4 * max(1.0, abs(v_empty_ref))
+    assert abs(v[2].item() - r1["v_full"]) <= 1e-6 * max(1.0, abs(r1["v_full"]))

@@ -124,6 +124,66 @@ def test_frequency_table_matches_oracle():
     assert torch.equal(unet.timestep_frequencies(64), ounet.timestep_frequencies(64))
 
 
+def test_classifier_spec_and_no_cpu_fallback():
+    from oracle import resnet18 as ores
+    from synt_isic_amd.classifier import HipMelanomaClassifier
+    assert list(arch.resnet18_param_spec(7).items()) == list(ores.param_spec(7).items())
+    assert ores.num_trainable_params(7) == 11_180_103
+    assert len(arch.resnet18_param_spec(7)) == 102
+    sd = weights.synthetic_resnet18_state_dict()
+    m = HipMelanomaClassifier(num_classes=7, pretrained=False)
+    m.load_state_dict(sd)
+    assert sum(p.numel() for p in m.parameters()) == 11_180_103
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(NotImplementedError):
+        HipMelanomaClassifier(pretrained=True)               # a network download in the reference (XAI.py:389)
+    # non-strict load keeps only name+shape matches (XAI.py:518-527): an 8-way fc is skipped, the rest is taken
+    other = dict(weights.synthetic_resnet18_state_dict(seed=1, num_classes=8))
+    m.load_state_dict(other, strict=False)
+    got = m.state_dict()
+    assert torch.equal(got["model.fc.weight"], sd["model.fc.weight"])
+    assert torch.equal(got["model.conv1.weight"], other["model.conv1.weight"])
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(other, strict=True)
+
+
+def test_oracle_classifier_matches_torch_modules():
+    """The functional restatement equals the same network assembled from torch.nn modules (BasicBlock form)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle import resnet18 as ores
+    sd = weights.synthetic_resnet18_state_dict()
+
+    def conv_bn(prefix_c, prefix_b, cin, cout, k, stride):
+        c = nn.Conv2d(cin, cout, k, stride, k // 2, bias=False)
+        b = nn.BatchNorm2d(cout)
+        c.weight.data = sd[prefix_c + ".weight"]
+        b.weight.data, b.bias.data = sd[prefix_b + ".weight"], sd[prefix_b + ".bias"]
+        b.running_mean, b.running_var = sd[prefix_b + ".running_mean"], sd[prefix_b + ".running_var"]
+        return nn.Sequential(c, b).eval()
+
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        h = ores.preprocess_for_classifier(x)
+        h = F.max_pool2d(F.relu(conv_bn("model.conv1", "model.bn1", 3, 64, 7, 2)(h)), 3, 2, 1)
+        cin = 64
+        for l, width in enumerate((64, 128, 256, 512)):
+            for j in range(2):
+                stride = 2 if (l > 0 and j == 0) else 1
+                base = f"model.layer{l + 1}.{j}"
+                out = F.relu(conv_bn(base + ".conv1", base + ".bn1", cin, width, 3, stride)(h))
+                out = conv_bn(base + ".conv2", base + ".bn2", width, width, 3, 1)(out)
+                idn = h if (stride == 1 and cin == width) else conv_bn(base + ".downsample.0", base + ".downsample.1",
+                                                                     cin, width, 1, stride)(h)
+                h = F.relu(out + idn)
+                cin = width
+        logits = F.linear(F.adaptive_avg_pool2d(h, 1).flatten(1), sd["model.fc.weight"], sd["model.fc.bias"])
+        ref = ores.classifier_forward(sd, x)
+    torch.testing.assert_close(logits, ref, rtol=1e-5, atol=1e-5)
+    assert ref.shape == (2, 7) and torch.isfinite(ref).all()
+
+
 def test_product_does_not_import_oracle():
     import os
     import re
