@@ -80,7 +80,14 @@ typedef struct sisic_conv_args {
     int relu;               /* 1: max(0, .) after everything (classifier) */
     float* out;             /* dev [B,Cout,Hout,Wout]                     */
     int tile_cfg;           /* 0 = auto; >0 forces a tile configuration (tests/tuning) */
+    const float* w_winograd; /* dev, layout of sisic_conv_winograd_pack, or NULL: when given, 3x3 stride-1
+                                convolutions may run as Winograd F(2x2,3x3) (tile_cfg 60/61 force it)        */
 } sisic_conv_args;
+
+/* Winograd-domain filters U = G g G^T of an OIHW 3x3 weight, computed in float64:
+ * number of floats, and dev OIHW -> dev packed [Cin_pad][16][Cout_pad].                      */
+int64_t sisic_conv_winograd_numel(int Cout, int Cin);
+int sisic_conv_winograd_pack(sisic_ctx*, const float* w_oihw, int Cout, int Cin, float* u_packed, void* stream);
 
 /* number of floats of the packed form of an OIHW weight [Cout,Cin,k,k] */
 int64_t sisic_conv_packed_numel(int Cout, int Cin, int ksize);

@@ -35,6 +35,7 @@ class ConvArgs(C.Structure):
         ("chan_bias", C.c_void_p), ("chan_bias_stride", C.c_int),
         ("residual", C.c_void_p), ("relu", C.c_int),
         ("out", C.c_void_p), ("tile_cfg", C.c_int),
+        ("w_winograd", C.c_void_p),
     ]
 
 
@@ -58,6 +59,8 @@ SIGNATURES = {
     "sisic_destroy": (C.c_int, [C.c_void_p]),
     "sisic_conv_packed_numel": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sisic_conv_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "sisic_conv_winograd_numel": (C.c_int64, [C.c_int, C.c_int]),
+    "sisic_conv_winograd_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sisic_conv2d": (C.c_int, [C.c_void_p, C.POINTER(ConvArgs), C.c_void_p]),
     "sisic_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -108,6 +108,16 @@ int sisic_conv_pack_weights(sisic_ctx* ctx, const float* w, int Cout, int Cin, i
     return launch_conv_pack(ctx, w, Cout, Cin, ksize, packed, static_cast<hipStream_t>(stream));
 }
 
+int64_t sisic_conv_winograd_numel(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return -1;
+    return winograd_packed_numel(Cout, Cin);
+}
+
+int sisic_conv_winograd_pack(sisic_ctx* ctx, const float* w, int Cout, int Cin, float* packed, void* stream) {
+    SISIC_REQUIRE(ctx && w && packed && Cout > 0 && Cin > 0, "conv_winograd_pack: bad arguments");
+    return launch_winograd_pack(ctx, w, Cout, Cin, packed, static_cast<hipStream_t>(stream));
+}
+
 int sisic_conv2d(sisic_ctx* ctx, const sisic_conv_args* args, void* stream) {
     SISIC_REQUIRE(ctx && args, "conv2d: null argument");
     return launch_conv2d(ctx, *args, static_cast<hipStream_t>(stream));

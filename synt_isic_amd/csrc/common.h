@@ -88,6 +88,11 @@ inline int conv_cout_pad(int cout) { return round_up(cout, CONV_CO_TILE); }
 
 // launchers implemented in the .hip files
 int launch_conv2d(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
+int launch_conv_smallcout(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
+// conv_winograd.hip: F(2x2,3x3) for 3x3 stride-1 convolutions
+int launch_conv_winograd(sisic_ctx*, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s);
+int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s);
+int64_t winograd_packed_numel(int Cout, int Cin);
 int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float* packed, hipStream_t s);
 int launch_gn_stats(sisic_ctx*, const float* in0, int c0, const float* in1, int c1, int B, int HW, int groups,
                     float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s);

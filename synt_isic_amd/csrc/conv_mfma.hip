@@ -77,8 +77,8 @@ struct ConvGeom {
     static_assert(CIC % 2 == 0, "two channels per MFMA");
 };
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC>
-__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma_kernel(const ConvParams p) {
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC, int OCC>
+__global__ void __launch_bounds__(64 * WM * WN, OCC) conv_mfma_kernel(const ConvParams p) {
     using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const in_lds = smem;                    // [2][IN_BUF]
@@ -311,7 +311,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
     }
 }
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC, int OCC = 2>
 static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
     using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
     p.tiles_x = cdiv(p.Wout, TW);
@@ -321,7 +321,7 @@ static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
     const int64_t nwg = (int64_t)p.B * p.tiles_x * p.tiles_y * p.n_co_tiles;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d: grid of %lld workgroups unsupported", (long long)nwg);
     p.nwg = (int)nwg;
-    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
+    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -346,6 +346,7 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 // Tile configurations.  id -> (KS, STRIDE, MT, NT, WM, WN, TW):
 //   3x3 s1:  1: 2,2,1,4,TW64   2: 2,2,1,4,TW32   3: 2,2,1,4,TW16   4: 1,1,2,2,TW8   5: 2,1,1,4,TW16 (PIX128)
 //            6: 2,1,1,4,TW64   7: 2,1,1,4,TW32 (PIX128)   8: 1,2,2,4,TW32   9: 1,2,2,4,TW16 (8 waves, PIX256)
+//           14: 1,1,2,4,TW16  15: 1,1,2,4,TW8 (8 waves, PIX128)   50: vector-ALU kernel for Cout <= 4
 //   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
 //   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
 //   1x1 s2: 31: 2,1,1,4,TW32  32: 2,1,1,4,TW16  33: 1,1,2,2,TW8      7x7 s2: 41: 2,1,1,4,TW32 (CIC 4)
@@ -381,6 +382,15 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
     ProfileScope prof(ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops);
 
     int cfg = a.tile_cfg;
+    if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50))
+        return launch_conv_smallcout(ctx, a, s);      // conv_out: vector-ALU kernel, conv_small.hip
+    if (a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr) {
+        // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs.  Auto: from 12x12 output up (64 tiles of one image fill a
+        // workgroup); the 8x8 level stays on the direct kernel (too few workgroups of 4 images x 64 channels).
+        if (cfg == 60 || cfg == 61) return launch_conv_winograd(ctx, a, a.w_winograd, cfg, s);
+        if (cfg == 0 && p.Hout >= 12 && p.Wout >= 12) return launch_conv_winograd(ctx, a, a.w_winograd, 60, s);
+    }
+    SISIC_REQUIRE(cfg != 60 && cfg != 61, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 4>(ctx, p, s);
@@ -411,8 +421,11 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
             case 5: return launch_cfg<3, 1, 2, 1, 1, 4, 16, 8>(ctx, p, s);
             case 6: return launch_cfg<3, 1, 2, 1, 1, 4, 64, 8>(ctx, p, s);
             case 7: return launch_cfg<3, 1, 2, 1, 1, 4, 32, 8>(ctx, p, s);
-            case 8: return launch_cfg<3, 1, 1, 2, 2, 4, 32, 8>(ctx, p, s);
-            case 9: return launch_cfg<3, 1, 1, 2, 2, 4, 16, 8>(ctx, p, s);
+            case 8: return launch_cfg<3, 1, 1, 2, 2, 4, 32, 8, 4>(ctx, p, s);
+            case 9: return launch_cfg<3, 1, 1, 2, 2, 4, 16, 8, 4>(ctx, p, s);
+            case 10: return launch_cfg<3, 1, 1, 2, 2, 4, 32, 8, 2>(ctx, p, s);
+            case 14: return launch_cfg<3, 1, 1, 1, 2, 4, 16, 8, 4>(ctx, p, s);
+            case 15: return launch_cfg<3, 1, 1, 1, 2, 4, 8, 8, 4>(ctx, p, s);
         }
     } else {
         if (cfg == 0) cfg = p.Wout >= 24 ? 11 : (p.Wout >= 12 ? 12 : 13);

@@ -5,9 +5,9 @@
 // The normalise+affine(+SiLU) half is fused into the consuming convolution's load path
 // (conv_mfma.hip), so the activation tensor is read once here and once by the conv.
 //
-// One workgroup per (sample, group): two passes over the group's cpg*HW elements
-// (mean, then centred sum of squares -- the second pass hits L2), wavefront-shuffle
-// reductions, then   scale[b,c] = gamma[c]*rstd,  shift[b,c] = beta[c] - mean*scale[b,c].
+// One workgroup per (sample, group): one pass over the group's cpg*HW elements accumulating
+// shifted first and second moments, wavefront-shuffle + LDS reductions, then
+//   scale[b,c] = gamma[c]*rstd,  shift[b,c] = beta[c] - mean*scale[b,c].
 // The input may be the channel concatenation of two tensors (up-path skip connections);
 // a group may straddle the seam.
 //
@@ -51,40 +51,34 @@ gn_stats_kernel(const float* __restrict__ in0, int c0, const float* __restrict__
         return (c < c0) ? in0 + ((size_t)b * c0 + c) * HW : in1 + ((size_t)b * c1 + (c - c0)) * HW;
     };
 
-    float s = 0.0f;
+    // ONE pass over the data with shifted sums: K = the group's first element, s1 = sum(x-K),
+    // s2 = sum((x-K)^2); mean = K + s1/n, var = s2/n - (s1/n)^2.  Shifting by a sample of the data keeps the
+    // cancellation in the variance benign (|mean-K| is O(std)), at half the memory traffic of two passes.
+    const float K = plane(g * cpg)[0];
+    float s1 = 0.0f, s2 = 0.0f;
     for (int j = 0; j < cpg; ++j) {
         const float* src = plane(g * cpg + j);
         if (vec) {
             const float4* s4 = reinterpret_cast<const float4*>(src);
             for (int i = tid; i < HW / 4; i += GN_THREADS) {
                 const float4 v = s4[i];
-                s += (v.x + v.y) + (v.z + v.w);
-            }
-        } else {
-            for (int i = tid; i < HW; i += GN_THREADS) s += src[i];
-        }
-    }
-    const float n = (float)cpg * (float)HW;
-    const float mean = block_sum(s, red) / n;
-
-    float q = 0.0f;
-    for (int j = 0; j < cpg; ++j) {
-        const float* src = plane(g * cpg + j);
-        if (vec) {
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            for (int i = tid; i < HW / 4; i += GN_THREADS) {
-                const float4 v = s4[i];
-                const float a = v.x - mean, bq = v.y - mean, c = v.z - mean, d = v.w - mean;
-                q += (a * a + bq * bq) + (c * c + d * d);
+                const float a = v.x - K, bq = v.y - K, c = v.z - K, d = v.w - K;
+                s1 += (a + bq) + (c + d);
+                s2 += (a * a + bq * bq) + (c * c + d * d);
             }
         } else {
             for (int i = tid; i < HW; i += GN_THREADS) {
-                const float a = src[i] - mean;
-                q += a * a;
+                const float a = src[i] - K;
+                s1 += a;
+                s2 += a * a;
             }
         }
     }
-    const float var = block_sum(q, red) / n;
+    const float n = (float)cpg * (float)HW;
+    const float m1 = block_sum(s1, red) / n;
+    const float m2 = block_sum(s2, red) / n;
+    const float mean = K + m1;
+    const float var = fmaxf(m2 - m1 * m1, 0.0f);
     const float rstd = 1.0f / sqrtf(var + eps);
     if (tid < cpg) {
         const int c = g * cpg + tid;

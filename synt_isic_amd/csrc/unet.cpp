@@ -13,6 +13,7 @@
 // to the host between steps.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -27,6 +28,8 @@ struct ConvW {            // one convolution's parameters
     int cout = 0, cin = 0, k = 0;
     int w_idx = -1, b_idx = -1;   // indices into the state-dict tensor table (raw)
     float* packed = nullptr;      // device, packed layout
+    float* wino = nullptr;        // device, Winograd-domain filters (3x3 stride-1 convolutions only)
+    bool strided = false;         // stride-2 downsampler: no Winograd form
     const float* bias = nullptr;  // device
 };
 
@@ -115,6 +118,7 @@ struct sisic_unet {
     uint64_t stage_next = 0;
     hipEvent_t stage_ev[STAGE_SLOTS] = {};
     bool stage_used[STAGE_SLOTS] = {};
+    bool use_winograd = true;    // SISIC_WINOGRAD=0 in the environment keeps every 3x3 on the direct kernel
     float* eps_buf = nullptr;    // sampling loop scratch [B,C,H,W]
     size_t eps_floats = 0;
 
@@ -240,6 +244,10 @@ int prepare_conv(sisic_unet* u, ConvW& c) {
     SISIC_TRY(dev_alloc(u, (size_t)sisic_conv_packed_numel(c.cout, c.cin, c.k), &c.packed));
     SISIC_TRY(launch_conv_pack(u->ctx, u->rawp(c.w_idx), c.cout, c.cin, c.k, c.packed, nullptr));
     c.bias = u->rawp(c.b_idx);
+    if (c.k == 3 && !c.strided && c.cout > 4) {
+        SISIC_TRY(dev_alloc(u, (size_t)winograd_packed_numel(c.cout, c.cin), &c.wino));
+        SISIC_TRY(launch_winograd_pack(u->ctx, u->rawp(c.w_idx), c.cout, c.cin, c.wino, nullptr));
+    }
     return SISIC_OK;
 }
 void prepare_norm(sisic_unet* u, NormW& n) {
@@ -296,7 +304,10 @@ int prepare_all(sisic_unet* u) {
     for (auto& blk : u->down_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a));
     for (auto& blk : u->up_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a));
     SISIC_TRY(prepare_attn(u, u->mid_attn));
-    for (auto& c : u->downsamplers) SISIC_TRY(prepare_conv(u, c));
+    for (auto& c : u->downsamplers) {
+        c.strided = true;
+        SISIC_TRY(prepare_conv(u, c));
+    }
     for (auto& c : u->upsamplers) SISIC_TRY(prepare_conv(u, c));
     SISIC_HIP(hipDeviceSynchronize());
     return SISIC_OK;
@@ -405,6 +416,7 @@ struct Fwd {
         a.in0 = in0; a.c0 = c0; a.in1 = in1; a.c1 = c1;
         a.B = B; a.Hin = H; a.Win = W; a.upsample = ups; a.ksize = c.k; a.stride = stride;
         a.w_packed = c.packed; a.bias = c.bias; a.Cout = c.cout;
+        a.w_winograd = (stride == 1 && u->use_winograd) ? c.wino : nullptr;
         if (gn_prologue) { a.gn_scale = u->gn_scale; a.gn_shift = u->gn_shift; a.gn_silu = silu ? 1 : 0; }
         a.chan_bias = chan_bias; a.chan_bias_stride = tproj_stride;
         a.residual = residual; a.out = out;
@@ -591,6 +603,7 @@ int sisic_unet_create(sisic_ctx* ctx, const sisic_unet_config* cfg, sisic_unet**
     u->ctx = ctx;
     u->cfg = *cfg;
     u->freqs.assign(cfg->freqs, cfg->freqs + cfg->n_freqs);
+    if (const char* e = std::getenv("SISIC_WINOGRAD")) u->use_winograd = std::atoi(e) != 0;
     u->cfg.freqs = nullptr;
     const int rc = describe(u);
     if (rc != SISIC_OK) { delete u; return rc; }

@@ -58,9 +58,21 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
+    """OIHW 3x3 -> Winograd-domain filters G g G^T, [Cin_pad][16][Cout_pad] (sisic_conv_winograd_pack)."""
+    lib = _lib.load()
+    cout, cin, k, k2 = w.shape
+    if k != 3 or k2 != 3:
+        raise ValueError("Winograd F(2x2,3x3) needs a 3x3 weight")
+    out = torch.empty(lib.sisic_conv_winograd_numel(cout, cin), dtype=torch.float32, device=w.device)
+    check(lib.sisic_conv_winograd_pack(context(w.device), _ptr(w, "weight"), cout, cin, out.data_ptr(),
+                                       _stream(w.device)))
+    return out
+
+
 def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bias=None, x2=None, stride=1,
            upsample=False, gn_scale=None, gn_shift=None, gn_silu=False, chan_bias=None, residual=None,
-           relu=False, tile_cfg=0) -> torch.Tensor:
+           relu=False, tile_cfg=0, w_winograd=None) -> torch.Tensor:
     lib = _lib.load()
     B, c0, H, W = x.shape
     c1 = 0 if x2 is None else x2.shape[1]
@@ -78,6 +90,7 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bi
     a.chan_bias = _ptr(chan_bias, "chan_bias"); a.chan_bias_stride = cout if chan_bias is not None and chan_bias.dim() == 2 and chan_bias.shape[0] == B else 0
     a.residual = _ptr(residual, "residual"); a.relu = int(relu)
     a.out = out.data_ptr(); a.tile_cfg = tile_cfg
+    a.w_winograd = _ptr(w_winograd, "w_winograd")
     check(lib.sisic_conv2d(context(x.device), C.byref(a), _stream(x.device)))
     return out
 

@@ -67,7 +67,7 @@ def _run_conv(x, w, cfg, **kw):
 # (cfg, H, W) -- natural shapes for each tile configuration plus ragged ones that exercise the masks
 CONV3_S1 = [(1, 64, 64), (1, 12, 70), (2, 32, 32), (2, 20, 40), (3, 16, 16), (3, 24, 24), (4, 8, 8), (4, 9, 5),
             (5, 16, 16), (6, 64, 64), (6, 10, 70), (7, 32, 32), (7, 9, 40), (8, 32, 32), (8, 20, 40), (9, 16, 16),
-            (9, 24, 20), (0, 64, 64), (0, 8, 8)]
+            (9, 24, 20), (14, 16, 16), (14, 20, 12), (15, 8, 8), (15, 16, 24), (0, 64, 64), (0, 8, 8)]
 
 
 @pytest.mark.parametrize("cfg,H,W", CONV3_S1)
@@ -83,8 +83,29 @@ def test_conv3x3_channel_edges(cin, cout):
     x = _rand(2, cin, 16, 32, seed=4)
     w = _rand(cout, cin, 3, 3, seed=5, scale=0.1)
     b = _rand(cout, seed=6)
-    for cfg in (0, 1, 4):
+    for cfg in (0, 1, 4, 14):
         _close(_run_conv(x, w, cfg, bias=b), _conv_ref(x, w, b), what=f"conv3x3 {cin}->{cout} cfg{cfg}")
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (16, 16), (20, 36), (5, 7)])
+def test_conv3x3_small_cout_kernel(H, W):
+    """Cout <= 4 takes the vector-ALU kernel (conv_small.hip, tile_cfg 50 / auto): every fused feature."""
+    B, c0, c1 = 2, 20, 12
+    x, x2 = _rand(B, c0, H, W, seed=80), _rand(B, c1, H, W, seed=81)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=82), 0.3 * _rand(B, c0 + c1, seed=83))
+    for cout in (1, 3, 4):
+        w = _rand(cout, c0 + c1, 3, 3, seed=84 + cout, scale=0.1)
+        b = _rand(cout, seed=90 + cout)
+        res = _rand(B, cout, H, W, seed=95 + cout)
+        cb = _rand(B, cout, seed=99 + cout)
+        for cfg in (0, 50):
+            kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True)
+            _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"small-cout {cout} cfg{cfg} {H}x{W}")
+            kw = dict(bias=b, x2=x2, gn=gn, gn_silu=False, chan_bias=cb, residual=res, relu=True)
+            _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"small-cout fused {cout} cfg{cfg}")
+    w = _rand(3, 64, 3, 3, seed=101, scale=0.05)
+    x = _rand(1, 64, H, W, seed=102)
+    _close(_run_conv(x, w, 0), _conv_ref(x, w), what="small-cout plain 64->3")
 
 
 def test_conv3x3_no_bias_and_identity_weight():
@@ -125,6 +146,64 @@ def test_conv3x3_fused_everything(cfg, H, W):
     kw = dict(bias=b, x2=x2, chan_bias=cb[0])
     ref = _conv_ref(x, w, bias=b, x2=x2, chan_bias=cb[0:1].expand(B, -1))
     _close(_run_conv(x, w, cfg, **kw), ref, what=f"broadcast chan_bias cfg{cfg}")
+
+
+def _run_wino(x, w, cfg, **kw):
+    from synt_isic_amd import ops
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    gn = kw.get("gn")
+    return ops.conv2d(d(x), ops.pack_conv_weight(d(w)), w.shape[0], 3, bias=d(kw.get("bias")), x2=d(kw.get("x2")),
+                      upsample=kw.get("upsample", False), gn_scale=d(gn[0]) if gn else None,
+                      gn_shift=d(gn[1]) if gn else None, gn_silu=kw.get("gn_silu", False),
+                      chan_bias=d(kw.get("chan_bias")), residual=d(kw.get("residual")), relu=kw.get("relu", False),
+                      tile_cfg=cfg, w_winograd=ops.pack_winograd_weight(d(w)))
+
+
+@pytest.mark.parametrize("cfg,B,H,W", [(60, 2, 16, 16), (60, 2, 64, 64), (60, 1, 32, 48), (60, 3, 18, 10), (60, 2, 9, 23),
+                                       (61, 8, 8, 8), (61, 5, 8, 8), (61, 3, 6, 10), (0, 2, 32, 32), (0, 2, 8, 8)])
+def test_conv3x3_winograd(cfg, B, H, W):
+    """Winograd F(2x2,3x3) on the MFMA pipe == the float64 convolution, plain and with every fused feature
+    (cfg 60: 8x8 tiles of one image; 61: 4 images x 4x4 tiles; 0: auto dispatch with Winograd filters present)."""
+    c0, c1, cout = 20, 12, 70                        # seam inside a chunk, Cout not a multiple of 64
+    x, x2 = _rand(B, c0, H, W, seed=110), _rand(B, c1, H, W, seed=111)
+    w = _rand(cout, c0 + c1, 3, 3, seed=112, scale=0.1)
+    b = _rand(cout, seed=113)
+    _close(_run_wino(x, w[:, :c0].contiguous(), cfg, bias=b), _conv_ref(x, w[:, :c0], b), what=f"winograd plain cfg{cfg}")
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=114), 0.3 * _rand(B, c0 + c1, seed=115))
+    cb = _rand(B, cout, seed=116)
+    res = _rand(B, cout, H, W, seed=117)
+    kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True, chan_bias=cb, residual=res)
+    _close(_run_wino(x, w, cfg, **kw), _conv_ref(x, w, **kw), tol=3e-5, what=f"winograd fused cfg{cfg}")
+    kw = dict(bias=b, x2=x2, gn=gn, gn_silu=False, relu=True, chan_bias=cb[0])
+    ref = _conv_ref(x, w, bias=b, x2=x2, gn=gn, relu=True, chan_bias=cb[0:1].expand(B, -1))
+    _close(_run_wino(x, w, cfg, **kw), ref, tol=3e-5, what=f"winograd fused 2 cfg{cfg}")
+
+
+@pytest.mark.parametrize("cfg,H,W", [(60, 16, 16), (60, 8, 8), (60, 10, 14), (61, 4, 4)])
+def test_conv3x3_winograd_upsample(cfg, H, W):
+    x = _rand(2, 24, H, W, seed=120)
+    w = _rand(64, 24, 3, 3, seed=121, scale=0.1)
+    b = _rand(64, seed=122)
+    _close(_run_wino(x, w, cfg, bias=b, upsample=True), _conv_ref(x, w, b, upsample=True), what=f"winograd upsample cfg{cfg}")
+
+
+def test_conv3x3_winograd_reference_layers_and_identity():
+    # identity filter: the transform pair must reproduce the input up to fp32 rounding of the 1/2, 1/4 weights
+    C = 64
+    x = _rand(1, C, 16, 16, seed=123)
+    w = torch.zeros(C, C, 3, 3)
+    for c in range(C):
+        w[c, c, 1, 1] = 1.0
+    _close(_run_wino(x, w, 60), x.double(), tol=1e-6, what="winograd identity")
+    for i, (cin, cout, r) in enumerate([(64, 64, 64), (192, 64, 64), (384, 128, 32), (512, 256, 16), (3, 64, 64)]):
+        xx = _rand(1, cin, r, r, seed=130 + i)
+        ww = _rand(cout, cin, 3, 3, seed=140 + i, scale=(cin * 9) ** -0.5)
+        bb = _rand(cout, seed=150 + i, scale=0.1)
+        _close(_run_wino(xx, ww, 60, bias=bb), _conv_ref(xx, ww, bb), what=f"winograd layer {cin}->{cout}@{r}")
+    from synt_isic_amd import ops
+    from synt_isic_amd._lib import SisicError
+    with pytest.raises(SisicError, match="w_winograd"):
+        ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV)), C, 3, tile_cfg=60)
 
 
 def test_gn_prologue_keeps_padding_zero():

@@ -56,7 +56,7 @@ def cfgs_for(k, stride, which):
         return [0, 21, 22, 23]
     if stride == 2:
         return [0, 11, 12, 13]
-    return [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+    return [8, 9, 4, 60, 61, 0]
 
 
 def main():
@@ -78,6 +78,7 @@ def main():
         x2 = torch.randn(B, c1, H, W, device=dev) if c1 else None
         w = torch.randn(cout, c0 + c1, k, k, device=dev) * 0.05
         wp = ops.pack_conv_weight(w)
+        wino = ops.pack_winograd_weight(w) if (k == 3 and stride == 1 and cout > 4) else None
         bias = torch.randn(cout, device=dev)
         Hc = 2 * H if ups else H
         Ho = (Hc + 2 * (k // 2) - k) // stride + 1
@@ -90,7 +91,8 @@ def main():
         for cfg in cfgs_for(k, stride, args.cfgs):
             def run():
                 return ops.conv2d(x, wp, cout, k, bias=bias, x2=x2, stride=stride, upsample=bool(ups),
-                                  gn_scale=gs, gn_shift=gb, gn_silu=bool(gn), residual=r, tile_cfg=cfg)
+                                  gn_scale=gs, gn_shift=gb, gn_silu=bool(gn), residual=r, tile_cfg=cfg,
+                                  w_winograd=wino if cfg in (0, 60, 61) else None)
             try:
                 run()
             except Exception as e:  # cfg not applicable
