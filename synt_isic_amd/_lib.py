@@ -10,7 +10,8 @@ import ctypes as C
 import os
 from typing import Optional
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsisic_hip.so")
+_LIB_PATH = os.environ.get("SISIC_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                             "libsisic_hip.so")
 _lib: Optional[C.CDLL] = None
 
 SISIC_OK = 0

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(CS_THR) conv3x3_smallcout_kernel(const ConvSma
         for (int i = 0; i < CS_EPT; ++i) {
             float v = rin[i];
             if (prologue) v = v * gsc + gsh;
-            if (prologue == 2) v = __fdividef(v, 1.0f + __expf(-v));
+            if (prologue == 2) v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
             dst[i * CS_TPC] = ((m >> i) & 1u) ? v : 0.0f;
         }
         if (tid < CS_CIC * 9) *reinterpret_cast<float4*>(&w_lds[buf][tid * 4]) = make_float4(rw[0], rw[1], rw[2], rw[3]);

@@ -20,6 +20,12 @@
 // small multiple of the direct kernel's (tests: same 2e-5 * max(1,|ref|) bound).
 #include "common.h"
 
+// Timing-only ablation builds for tools/conv_bench.py (results are wrong): bit 0 skips the MFMAs, bit 1 the
+// output transform, bit 2 the halo staging + input transform.  Never defined in the shipped library.
+#ifndef WINO_ABLATE
+#define WINO_ABLATE 0
+#endif
+
 namespace sisic {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -44,36 +50,55 @@ struct WinoParams {
     int relu;
     float* out;
     int groups_x, groups_y, groups_b, n_co_tiles, nwg, nchunks;
+    int stagger;        // 1: half of the waves run MFMA-first, the other half stage-first (see the channel loop)
 };
 
-constexpr int WG_THREADS = 512;
 constexpr int W_CIC = 8;            // input channels per chunk
 constexpr int W_TILES = 64;         // 2x2 output tiles per workgroup
 constexpr int W_CO = 64;            // output channels per workgroup
 constexpr int W_SLAB = W_CIC * 16 * 64;   // floats of one U or V buffer (32 KiB)
 
-__device__ __forceinline__ float wsilu(float v) { return __fdividef(v, 1.0f + __expf(-v)); }
+// Makes a wave-uniform pointer provably uniform for hipcc (two v_readfirstlane), so that the loads through it use the
+// scalar-base form  global_load v, v_offset32, s[base:base+1]  instead of per-lane 64-bit address arithmetic.
+__device__ __forceinline__ const char* uniform_ptr(const void* ptr) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
 
-template <int NIMG, int TY, int TX>
+// x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp): __fdividef expands to the 10-instruction IEEE
+// division sequence, and every VALU instruction in this loop displaces matrix work (tools/mfma_valu_probe.hip).
+__device__ __forceinline__ float wsilu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// NW = waves per workgroup: 8 (two transform positions xi per wave, 128 accumulator registers, 2 waves/SIMD)
+//                       or 16 (one xi per wave, 64 accumulator registers, 4 waves/SIMD).
+template <int NIMG, int TY, int TX, int NW>
 struct WinoGeom {
     static_assert(NIMG * TY * TX == W_TILES, "64 tiles per workgroup");
+    static_assert(NW == 8 || NW == 16, "8 or 16 waves");
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int XPW = 16 / NW;                       // transform positions per wave
     static constexpr int HH = 2 * TY + 2, HWD = 2 * TX + 2;   // halo extent per image
     static constexpr int HPI = HH * HWD;
     static constexpr int HEL = NIMG * HPI;                    // halo elements per channel
-    static constexpr int TPC = WG_THREADS / W_CIC;            // 64 threads stage one channel
+    static constexpr int TPC = THREADS / W_CIC;               // threads staging one channel
     static constexpr int EPT = (HEL + TPC - 1) / TPC;
     static constexpr int CHS = EPT * TPC;                     // padded channel stride in LDS
-    static constexpr size_t LDS_BYTES = (size_t)(4 * W_SLAB + W_CIC * CHS) * sizeof(float);
+    static constexpr int HBUF = W_CIC * CHS;
+    static constexpr int UPT = (W_SLAB / 4) / THREADS;        // float4 of the U slab per thread
+    static constexpr size_t LDS_BYTES = (size_t)(4 * W_SLAB + 2 * HBUF) * sizeof(float);
     static_assert(EPT <= 32, "valid mask is 32 bits");
+    static_assert(CHS % 2 == 0 && HPI % 2 == 0, "float2 transform reads need even strides");
 };
 
-template <int NIMG, int TY, int TX>
-__global__ void __launch_bounds__(WG_THREADS, 2) conv_winograd_kernel(const WinoParams p) {
-    using G = WinoGeom<NIMG, TY, TX>;
+template <int NIMG, int TY, int TX, int PRO, int NW>   // PRO: 0 = no prologue, 1 = GroupNorm apply, 2 = + SiLU
+__global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const WinoParams p) {
+    using G = WinoGeom<NIMG, TY, TX, NW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const U_lds = smem;                   // [2][W_SLAB]   ([ci][xi][co])
     float* const V_lds = smem + 2 * W_SLAB;      // [2][W_SLAB]   ([ci][xi][tile])
-    float* const H_lds = smem + 4 * W_SLAB;      // [W_CIC][CHS]  halo tile of the chunk being transformed
+    float* const H_lds = smem + 4 * W_SLAB;      // [2][HBUF]     staged halo tiles (prologue applied)
     float* const M_lds = smem;                   // epilogue: [16 xi][16 co][64 tiles] over the U/V buffers
 
     int work;
@@ -92,14 +117,21 @@ __global__ void __launch_bounds__(WG_THREADS, 2) conv_winograd_kernel(const Wino
     const int co0 = co_t * W_CO;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int HWin = p.Hin * p.Win, Cin = p.c0 + p.c1;
-    const int prologue = (p.gn_scale == nullptr) ? 0 : (p.gn_silu ? 2 : 1);
 
-    // ---- halo staging plan: wave w stages channel w of the chunk, lanes stride over its halo elements
-    const int sci = wave, sl = lane;
-    int goff[G::EPT];
+    // ---- halo staging plan: TPC threads per channel of the chunk.  The staged channel is wave-uniform
+    // (TPC is a multiple of 64), which lets every chunk-dependent address term live in SGPRs: global loads take the
+    // form  scalar base pointer (per chunk) + 32-bit per-thread byte offset (loop-invariant), i.e. the saddr
+    // encoding of global_load, and the channel loop carries no vector address arithmetic at all.
+    // (__builtin_amdgcn_raw_buffer_load_b128 is NOT used: hipcc 7.2 lowers it to a single buffer_load_dword.)
+    // (only the staged channel is made provably uniform: a scalar `wave` makes hipcc unswitch the loops and spill)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int sci = (G::TPC == 64) ? wave_u : (wave_u >> 1);
+    const int sl = tid % G::TPC;
+    unsigned goff[G::EPT];        // BYTE offset of the element inside its (image, channel) plane
     int gimg[G::EPT];
     unsigned vmask = 0;
 #pragma unroll
@@ -109,25 +141,33 @@ __global__ void __launch_bounds__(WG_THREADS, 2) conv_winograd_kernel(const Wino
         const int yy = r / G::HWD, xx = r % G::HWD;
         const int y = oy0 - 1 + yy, x = ox0 - 1 + xx;
         const bool v = e < G::HEL && (b0 + img) < p.B && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
-        goff[i] = v ? ((y >> p.ups) * p.Win + (x >> p.ups)) : 0;
+        goff[i] = v ? 4u * (unsigned)((y >> p.ups) * p.Win + (x >> p.ups)) : 0u;
         gimg[i] = v ? img : 0;
         vmask |= (v ? 1u : 0u) << i;
     }
+    unsigned uoff[G::UPT];        // byte offset of this thread's float4 inside a filter slab
+#pragma unroll
+    for (int i = 0; i < G::UPT; ++i) {
+        const int f = tid + i * G::THREADS;                // 2048 float4 per slab
+        uoff[i] = 4u * (unsigned)((f >> 4) * p.cout_pad + (f & 15) * 4);
+    }
 
-    // ---- transform plan: wave = channel, lane = tile
+    // ---- transform plan: lane = tile; NW=8: wave = channel (whole 4x4 patch); NW=16: wave = (channel, row half)
+    const int xci = (NW == 8) ? wave : (wave >> 1);
+    const int xrh = (NW == 8) ? 0 : (wave & 1);
     int xf_base;
     {
         const int t = lane;
         const int img = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
-        xf_base = sci * G::CHS + img * G::HPI + (2 * ty) * G::HWD + 2 * tx;
+        xf_base = xci * G::CHS + img * G::HPI + (2 * ty) * G::HWD + 2 * tx;
     }
 
-    // ---- MFMA operand bases: wave w owns xi = 2w, 2w+1
-    const int ab_base = half * 16 * 64 + (2 * wave) * 64 + l31;
+    // ---- MFMA operand bases: wave w owns xi = w*XPW .. w*XPW + XPW-1
+    const int ab_base = half * 16 * 64 + (wave * G::XPW) * 64 + l31;
 
-    f32x16 acc[2][2][2];     // [xi][co tile][tile tile]
+    f32x16 acc[G::XPW][2][2];     // [xi][co tile][tile tile]
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < G::XPW; ++x)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -135,94 +175,127 @@ __global__ void __launch_bounds__(WG_THREADS, 2) conv_winograd_kernel(const Wino
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][m][n][r] = 0.0f;
 
-    float rin[G::EPT];
-    float rw[16];
+    float rin[G::EPT];            // halo elements in flight (global -> registers -> H_lds)
+    float rw[G::UPT * 4];         // filter slab in flight
     float gsc = 1.0f, gsh = 0.0f;
     bool cval = false;
+    int hcc = 0;                  // channel of the halo data held in rin
 
-    auto load_chunk = [&](int chunk) {     // global -> registers (all loads unconditional at clamped addresses)
-        const int c = chunk * W_CIC + sci;
+    // All loads are unconditional at clamped, always-valid addresses and masked afterwards (see conv_mfma.hip).
+    auto load_halo = [&](int chunk) {
+        const int c = chunk * W_CIC + sci;                 // scalar
         cval = c < Cin;
-        const int cc = min(c, Cin - 1);
-        const bool first = cc < p.c0;
-        const float* src = first ? p.in0 + ((size_t)b0 * p.c0 + cc) * HWin : p.in1 + ((size_t)b0 * p.c1 + (cc - p.c0)) * HWin;
-        const size_t img_stride = (size_t)(first ? p.c0 : p.c1) * HWin;
+        hcc = min(c, Cin - 1);
+        const bool first = hcc < p.c0;
+        const int csrc = first ? p.c0 : p.c1;
+        const char* plane = uniform_ptr(
+            first ? p.in0 + ((size_t)b0 * p.c0 + hcc) * HWin : p.in1 + ((size_t)b0 * p.c1 + (hcc - p.c0)) * HWin);
+        const unsigned img_stride = 4u * (unsigned)(csrc * HWin);
 #pragma unroll
-        for (int i = 0; i < G::EPT; ++i) rin[i] = src[(NIMG > 1 ? gimg[i] * img_stride : 0) + goff[i]];
-        if (prologue) {
-            gsc = p.gn_scale[(size_t)b0 * Cin + cc];      // NIMG > 1: per-image scale/shift applied in stage_halo
-            gsh = p.gn_shift[(size_t)b0 * Cin + cc];
+        for (int i = 0; i < G::EPT; ++i) {
+            const unsigned vo = (NIMG > 1) ? (unsigned)gimg[i] * img_stride + goff[i] : goff[i];
+            rin[i] = *reinterpret_cast<const float*>(plane + vo);
         }
-        const float* usrc = p.u + (size_t)chunk * W_CIC * 16 * p.cout_pad + co0;
+        if constexpr (PRO != 0) {
+            gsc = p.gn_scale[b0 * Cin + hcc];              // uniform index: scalar loads.  NIMG > 1: see stage_halo
+            gsh = p.gn_shift[b0 * Cin + hcc];
+        }
+    };
+    auto load_u = [&](int chunk) {
+        const char* slab = uniform_ptr(p.u + (size_t)chunk * W_CIC * 16 * p.cout_pad + co0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + i * WG_THREADS;            // 2048 float4 per slab
-            const int rr = f >> 4, c4 = f & 15;
-            const float4 t = *reinterpret_cast<const float4*>(usrc + (size_t)rr * p.cout_pad + c4 * 4);
+        for (int i = 0; i < G::UPT; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(slab + uoff[i]);
             rw[4 * i + 0] = t.x; rw[4 * i + 1] = t.y; rw[4 * i + 2] = t.z; rw[4 * i + 3] = t.w;
         }
     };
-
-    auto stage = [&](int chunk, int buf) {      // registers -> H_lds (prologue applied) and U_lds[buf]
-        float* dst = H_lds + sci * G::CHS + sl;
+    auto stage_halo = [&](int hbuf) {            // registers -> H_lds[hbuf], prologue applied, padding zeroed after it
+        float* dst = H_lds + hbuf * G::HBUF + sci * G::CHS + sl;
         const unsigned m = cval ? vmask : 0u;
-        const int cc = min(chunk * W_CIC + sci, Cin - 1);
 #pragma unroll
         for (int i = 0; i < G::EPT; ++i) {
             float v = rin[i];
-            if (prologue) {
+            if constexpr (PRO != 0) {
                 float sc = gsc, sh = gsh;
-                if (NIMG > 1) {     // scale/shift differ per image of the group
+                if constexpr (NIMG > 1) {
                     const int bi = min(b0 + gimg[i], p.B - 1);
-                    sc = p.gn_scale[(size_t)bi * Cin + cc];
-                    sh = p.gn_shift[(size_t)bi * Cin + cc];
+                    sc = p.gn_scale[(size_t)bi * Cin + hcc];
+                    sh = p.gn_shift[(size_t)bi * Cin + hcc];
                 }
                 v = v * sc + sh;
-                if (prologue == 2) v = wsilu(v);
+                if constexpr (PRO == 2) v = wsilu(v);
             }
             dst[i * G::TPC] = ((m >> i) & 1u) ? v : 0.0f;
         }
+    };
+    auto stage_u = [&](int buf) {
         float* udst = U_lds + buf * W_SLAB + tid * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(udst + i * WG_THREADS * 4) =
+        for (int i = 0; i < G::UPT; ++i)
+            *reinterpret_cast<float4*>(udst + i * G::THREADS * 4) =
                 make_float4(rw[4 * i + 0], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]);
     };
-
-    auto transform = [&](int buf) {             // H_lds -> V_lds[buf]:  V = B^T d B for this wave's channel
-        const float* hp = H_lds + xf_base;
-        float d[4][4];
+    auto transform = [&](int hbuf, int vbuf) {   // H_lds[hbuf] -> V_lds[vbuf]:  V = B^T d B
+        const float* hp = H_lds + hbuf * G::HBUF + xf_base;
+        float* vp = V_lds + vbuf * W_SLAB + xci * 16 * 64 + lane;
+        if constexpr (NW == 8) {
+            float d[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float2 a = *reinterpret_cast<const float2*>(hp + i * G::HWD);
-            const float2 b = *reinterpret_cast<const float2*>(hp + i * G::HWD + 2);
-            d[i][0] = a.x; d[i][1] = a.y; d[i][2] = b.x; d[i][3] = b.y;
-        }
-        float t[4][4];
+            for (int i = 0; i < 4; ++i) {
+                const float2 a = *reinterpret_cast<const float2*>(hp + i * G::HWD);
+                const float2 b = *reinterpret_cast<const float2*>(hp + i * G::HWD + 2);
+                d[i][0] = a.x; d[i][1] = a.y; d[i][2] = b.x; d[i][3] = b.y;
+            }
+            float t[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0][j] = d[0][j] - d[2][j];
-            t[1][j] = d[1][j] + d[2][j];
-            t[2][j] = d[2][j] - d[1][j];
-            t[3][j] = d[1][j] - d[3][j];
-        }
-        float* vp = V_lds + buf * W_SLAB + sci * 16 * 64 + lane;
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vp[(4 * i + 0) * 64] = t[i][0] - t[i][2];
-            vp[(4 * i + 1) * 64] = t[i][1] + t[i][2];
-            vp[(4 * i + 2) * 64] = t[i][2] - t[i][1];
-            vp[(4 * i + 3) * 64] = t[i][1] - t[i][3];
+            for (int i = 0; i < 4; ++i) {
+                vp[(4 * i + 0) * 64] = t[i][0] - t[i][2];
+                vp[(4 * i + 1) * 64] = t[i][1] + t[i][2];
+                vp[(4 * i + 2) * 64] = t[i][2] - t[i][1];
+                vp[(4 * i + 3) * 64] = t[i][1] - t[i][3];
+            }
+        } else {
+            // this wave produces V rows 2*xrh and 2*xrh+1: it needs d rows xrh .. xrh+2
+            float d[3][4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float2 a = *reinterpret_cast<const float2*>(hp + (i + xrh) * G::HWD);
+                const float2 b = *reinterpret_cast<const float2*>(hp + (i + xrh) * G::HWD + 2);
+                d[i][0] = a.x; d[i][1] = a.y; d[i][2] = b.x; d[i][3] = b.y;
+            }
+            float t[2][4];
+            // xrh = 0: rows (d0,d1,d2): t0 = d0 - d2, t1 = d1 + d2;   xrh = 1: rows (d1,d2,d3): t2 = d2 - d1, t3 = d1 - d3
+            if (xrh) {          // wave-uniform: a branch, not 8 selects
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t[0][j] = d[1][j] - d[0][j]; t[1][j] = d[0][j] - d[2][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 2 * xrh + i;
+                vp[(4 * row + 0) * 64] = t[i][0] - t[i][2];
+                vp[(4 * row + 1) * 64] = t[i][1] + t[i][2];
+                vp[(4 * row + 2) * 64] = t[i][2] - t[i][1];
+                vp[(4 * row + 3) * 64] = t[i][1] - t[i][3];
+            }
         }
     };
-
-    auto mfma_part = [&](int buf, int cp0, int cp1) {
+    auto mfma_chunk = [&](int buf) {
         const float* A = U_lds + buf * W_SLAB + ab_base;
         const float* Bm = V_lds + buf * W_SLAB + ab_base;
 #pragma unroll
-        for (int cp = cp0; cp < cp1; ++cp) {
+        for (int cp = 0; cp < W_CIC / 2; ++cp) {
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
+            for (int x = 0; x < G::XPW; ++x) {
                 float a[2], b[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) a[m] = A[(2 * cp) * 16 * 64 + x * 64 + m * 32];
@@ -237,46 +310,94 @@ __global__ void __launch_bounds__(WG_THREADS, 2) conv_winograd_kernel(const Wino
         }
     };
 
-    // ---- software pipeline over the channel chunks
-    load_chunk(0);
-    stage(0, 0);
+    // ---- software pipeline over the channel chunks, ONE barrier per chunk.  Entering iteration c:
+    //   U/V[c&1] hold chunk c;  H[(c+1)&1] holds the staged halo of chunk c+1;  registers hold halo(c+2) and U(c+1).
+    const int n = p.nchunks;
+    load_halo(0);
+    load_u(0);
+    stage_halo(0);
+    stage_u(0);
+    if (n > 1) load_halo(1);
     __syncthreads();
-    transform(0);
-    if (p.nchunks > 1) load_chunk(1);
+    transform(0, 0);
+    if (n > 1) {
+        stage_halo(1);
+        load_u(1);
+    }
+    if (n > 2) load_halo(2);
     __syncthreads();
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const int buf = chunk & 1;
-        const bool more = chunk + 1 < p.nchunks;
-        if (more) stage(chunk + 1, buf ^ 1);              // H_lds <- chunk+1, U_lds[buf^1] <- chunk+1
-        mfma_part(buf, 0, 2);
-        __syncthreads();                                  // H_lds visible
-        if (more) transform(buf ^ 1);                     // V_lds[buf^1] <- chunk+1
-        if (chunk + 2 < p.nchunks) load_chunk(chunk + 2); // prefetch two chunks ahead into registers
-        mfma_part(buf, 2, 4);
-        __syncthreads();                                  // U/V[buf^1] visible, U/V[buf] free
+
+    // Phase stagger: all waves of the workgroup run the same program and meet at one barrier per chunk, so left
+    // alone they would all be in their staging phase (VALU/LDS) at the same time and all in their MFMA phase at the
+    // same time -- the matrix pipe then idles during staging and the time is the SUM of the two (measured).  Waves
+    // 0-3 (and 8-11) therefore issue the chunk's MFMAs FIRST and stage afterwards, waves 4-7 (and 12-15) stage
+    // first: every SIMD hosts one wave of each kind (waves are dealt to SIMDs round-robin), so its matrix pipe
+    // always has a wave feeding it while the partner wave does the vector/LDS work.  Everything inside one
+    // barrier interval touches disjoint buffers, so the order within the interval is free.
+    const bool mfma_first = p.stagger && (((wave >> 2) & 1) == 0);
+    int c = 0;
+    for (; c + 3 < n; ++c) {                 // steady state, branch-free per role: one basic block per chunk
+        if (mfma_first) {
+#if !(WINO_ABLATE & 1)
+            mfma_chunk(c & 1);
+#endif
+            transform((c + 1) & 1, (c + 1) & 1);
+            stage_u((c + 1) & 1);
+            stage_halo(c & 1);
+            load_halo(c + 3);
+            load_u(c + 2);
+        } else {
+#if !(WINO_ABLATE & 4)
+            transform((c + 1) & 1, (c + 1) & 1);
+#endif
+            stage_u((c + 1) & 1);
+#if !(WINO_ABLATE & 4)
+            stage_halo(c & 1);               // halo(c+2) -> H[c&1] (its previous content, halo(c), was consumed last iteration)
+#endif
+            load_halo(c + 3);
+            load_u(c + 2);
+#if !(WINO_ABLATE & 1)
+            mfma_chunk(c & 1);
+#endif
+        }
+        __syncthreads();
+    }
+    for (; c < n; ++c) {                     // last (up to) three chunks: same order, guarded
+        if (c + 1 < n) {
+            transform((c + 1) & 1, (c + 1) & 1);
+            stage_u((c + 1) & 1);
+        }
+        if (c + 2 < n) {
+            stage_halo(c & 1);
+            load_u(c + 2);
+        }
+#if !(WINO_ABLATE & 1)
+        mfma_chunk(c & 1);
+#endif
+        __syncthreads();
     }
 
     // ---- output transform: four rounds of 16 output channels through LDS
     const size_t HWout = (size_t)p.Hc * p.Wc;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
         const int mt = q >> 1, rbase = 8 * (q & 1);
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
+        for (int x = 0; x < G::XPW; ++x) {
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
+            for (int nn = 0; nn < 2; ++nn) {
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
                     const int r = rbase + rr;
                     const int row16 = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;     // row within the 16-channel block
-                    M_lds[((2 * wave + x) * 16 + row16) * 64 + n * 32 + l31] = acc[x][mt][n][r];
+                    M_lds[((wave * G::XPW + x) * 16 + row16) * 64 + nn * 32 + l31] = acc[x][mt][nn][r];
                 }
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pi = tid + k * WG_THREADS;       // 1024 (channel, tile) pairs
+        for (int k = 0; k < 1024 / G::THREADS; ++k) {
+            const int pi = tid + k * G::THREADS;       // 1024 (channel, tile) pairs
             const int co16 = pi >> 6, t = pi & 63;
             float m[4][4];
 #pragma unroll
@@ -303,17 +424,28 @@ __global__ void __launch_bounds__(WG_THREADS, 2) conv_winograd_kernel(const Wino
             if (p.bias) add += p.bias[coc];
             if (p.chan_bias) add += p.chan_bias[(size_t)bc * p.chan_bias_stride + coc];
             const size_t plane = ((size_t)bc * p.Cout + coc) * HWout;
+            size_t idx[2][2];
+            float res[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    idx[i][j] = plane + (size_t)min(oy + i, p.Hc - 1) * p.Wc + min(ox + j, p.Wc - 1);
+                    res[i][j] = 0.0f;
+                }
+            if (p.residual) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) res[i][j] = p.residual[idx[i][j]];
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int yy = oy + i, xx = ox + j;
-                    const bool in = ok && yy < p.Hc && xx < p.Wc;
-                    const size_t idx = plane + (size_t)min(yy, p.Hc - 1) * p.Wc + min(xx, p.Wc - 1);
-                    float v = y[i][j] + add;
-                    if (p.residual) v += p.residual[idx];
+                    float v = y[i][j] + add + res[i][j];
                     if (p.relu) v = fmaxf(v, 0.0f);
-                    if (in) p.out[idx] = v;
+                    if (ok && oy + i < p.Hc && ox + j < p.Wc) p.out[idx[i][j]] = v;
                 }
             }
         }
@@ -363,9 +495,9 @@ int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* p
 
 int64_t winograd_packed_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, W_CIC) * 16 * conv_cout_pad(Cout); }
 
-template <int NIMG, int TY, int TX>
+template <int NIMG, int TY, int TX, int PRO, int NW>
 static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
-    using G = WinoGeom<NIMG, TY, TX>;
+    using G = WinoGeom<NIMG, TY, TX, NW>;
     p.groups_x = cdiv(p.Wc, 2 * TX);
     p.groups_y = cdiv(p.Hc, 2 * TY);
     p.groups_b = cdiv(p.B, NIMG);
@@ -374,19 +506,29 @@ static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     const int64_t nwg = (int64_t)p.groups_x * p.groups_y * p.groups_b * p.n_co_tiles;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d(winograd): grid too large");
     p.nwg = (int)nwg;
-    auto kern = conv_winograd_kernel<NIMG, TY, TX>;
+    auto kern = conv_winograd_kernel<NIMG, TY, TX, PRO, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)G::LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(WG_THREADS), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(G::THREADS), G::LDS_BYTES, s, p);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
 
-// tile_cfg 60: 1 image x 8x8 tiles (16x16 output pixels);  61: 4 images x 4x4 tiles (8x8 output pixels each)
+template <int NIMG, int TY, int TX, int NW>
+static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
+    const int pro = (p.gn_scale == nullptr) ? 0 : (p.gn_silu ? 2 : 1);
+    if (pro == 2) return launch_wino<NIMG, TY, TX, 2, NW>(ctx, p, s);
+    if (pro == 1) return launch_wino<NIMG, TY, TX, 1, NW>(ctx, p, s);
+    return launch_wino<NIMG, TY, TX, 0, NW>(ctx, p, s);
+}
+
+// tile_cfg 60: 1 image x 8x8 tiles (16x16 output pixels), 8 waves;  61: 4 images x 4x4 tiles (8x8 outputs each), 8 waves;
+//          62 / 63: the same two tilings with 16 waves (one transform position per wave, 4 waves per SIMD)
+//          64..67 = 60..63 with the MFMA-first / stage-first phase stagger between SIMD partner waves
 int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s) {
     WinoParams p{};
     p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1;
@@ -398,8 +540,19 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
     p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu;
     p.out = a.out;
-    if (cfg == 61) return launch_wino<4, 4, 4>(ctx, p, s);
-    return launch_wino<1, 8, 8>(ctx, p, s);
+    SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 4 : 1) < 4294967296.0,
+                  "conv2d(winograd): per-thread load offsets are 32-bit; this tensor needs the direct kernel");
+    p.stagger = (cfg >= 64) ? 1 : 0;
+    switch (cfg) {
+        case 64: return launch_wino_pro<1, 8, 8, 8>(ctx, p, s);
+        case 65: return launch_wino_pro<4, 4, 4, 8>(ctx, p, s);
+        case 66: return launch_wino_pro<1, 8, 8, 16>(ctx, p, s);
+        case 67: return launch_wino_pro<4, 4, 4, 16>(ctx, p, s);
+        case 61: return launch_wino_pro<4, 4, 4, 8>(ctx, p, s);
+        case 62: return launch_wino_pro<1, 8, 8, 16>(ctx, p, s);
+        case 63: return launch_wino_pro<4, 4, 4, 16>(ctx, p, s);
+        default: return launch_wino_pro<1, 8, 8, 8>(ctx, p, s);
+    }
 }
 
 }  // namespace sisic

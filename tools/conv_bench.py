@@ -52,11 +52,13 @@ LAYERS = [
 def cfgs_for(k, stride, which):
     if which == "auto":
         return [0]
+    if which != "all":
+        return [int(c) for c in which.split(",")]
     if k == 1:
         return [0, 21, 22, 23]
     if stride == 2:
         return [0, 11, 12, 13]
-    return [8, 9, 4, 60, 61, 0]
+    return [60, 62, 0]
 
 
 def main():
@@ -65,6 +67,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--cfgs", default="all")
     ap.add_argument("--scale", type=int, default=1, help="multiply H (2 = the 128x128 configuration)")
+    ap.add_argument("--match", default="", help="only layers whose name contains this substring")
     args = ap.parse_args()
     dev = torch.device("cuda")
     B = args.batch
@@ -72,6 +75,8 @@ def main():
     total_flops = 0.0
     print(f"{'layer':34s} {'n':>2s} {'cfg':>3s} {'us':>9s} {'TFLOP/s':>8s} {'GB/s':>7s}")
     for (name, count, c0, c1, cout, H, k, stride, ups, gn, res) in LAYERS:
+        if args.match and args.match not in name:
+            continue
         H *= args.scale
         W = H
         x = torch.randn(B, c0, H, W, device=dev)
@@ -92,7 +97,7 @@ def main():
             def run():
                 return ops.conv2d(x, wp, cout, k, bias=bias, x2=x2, stride=stride, upsample=bool(ups),
                                   gn_scale=gs, gn_shift=gb, gn_silu=bool(gn), residual=r, tile_cfg=cfg,
-                                  w_winograd=wino if cfg in (0, 60, 61) else None)
+                                  w_winograd=wino if (cfg == 0 or 60 <= cfg <= 67) else None)
             try:
                 run()
             except Exception as e:  # cfg not applicable
@@ -106,10 +111,12 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             print(f"{name:34s} {count:2d} {cfg:3d} {us:9.1f} {flops / us / 1e6:8.1f} {byts / us / 1e3:7.0f}", flush=True)
-            if cfg == 0:
+            if cfg == 0 or "auto_us" not in dir():
                 auto_us = us
             if best is None or us < best[1]:
                 best = (cfg, us)
+        if best is None:
+            continue
         total_ms += count * auto_us / 1e3
         total_flops += count * flops
         if args.cfgs != "auto":
