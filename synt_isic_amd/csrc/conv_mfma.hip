@@ -387,11 +387,11 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
     if (a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr) {
         // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs.  Auto: from 12x12 output up (64 tiles of one image fill a
         // workgroup); the 8x8 level stays on the direct kernel (too few workgroups of 4 images x 64 channels).
-        if (cfg >= 60 && cfg <= 67) return launch_conv_winograd(ctx, a, a.w_winograd, cfg, s);
+        if (cfg >= 60 && cfg <= 71) return launch_conv_winograd(ctx, a, a.w_winograd, cfg, s);
         const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;   // per-thread offsets are 32-bit
         if (cfg == 0 && p.Hout >= 12 && p.Wout >= 12 && fits32) return launch_conv_winograd(ctx, a, a.w_winograd, 66, s);
     }
-    SISIC_REQUIRE(cfg < 60 || cfg > 67, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
+    SISIC_REQUIRE(cfg < 60 || cfg > 71, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 4>(ctx, p, s);

@@ -485,7 +485,7 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int Cout, int 
 }
 
 int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s) {
-    const int cin_pad = round_up(Cin, W_CIC), cout_pad = conv_cout_pad(Cout);
+    const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout);     // 16: the third form stages 16 channels at a time
     const size_t total = (size_t)cin_pad * cout_pad;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, cin_pad, cout_pad, packed);
@@ -493,7 +493,9 @@ int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* p
     return SISIC_OK;
 }
 
-int64_t winograd_packed_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, W_CIC) * 16 * conv_cout_pad(Cout); }
+int64_t winograd_packed_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * conv_cout_pad(Cout); }
+
+#include "conv_winograd3.inc"
 
 template <int NIMG, int TY, int TX, int PRO, int NW>
 static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
@@ -529,6 +531,7 @@ static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
 // tile_cfg 60: 1 image x 8x8 tiles (16x16 output pixels), 8 waves;  61: 4 images x 4x4 tiles (8x8 outputs each), 8 waves;
 //          62 / 63: the same two tilings with 16 waves (one transform position per wave, 4 waves per SIMD)
 //          64..67 = 60..63 with the MFMA-first / stage-first phase stagger between SIMD partner waves
+//          70 / 71: third form (conv_winograd3.inc): per-wave transform position, operands built in registers
 int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s) {
     WinoParams p{};
     p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1;
@@ -540,10 +543,12 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
     p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu;
     p.out = a.out;
-    SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 4 : 1) < 4294967296.0,
+    SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67 || cfg == 71) ? 4 : 1) < 4294967296.0,
                   "conv2d(winograd): per-thread load offsets are 32-bit; this tensor needs the direct kernel");
-    p.stagger = (cfg >= 64) ? 1 : 0;
+    p.stagger = (cfg >= 64 && cfg <= 67) ? 1 : 0;
     switch (cfg) {
+        case 70: return launch_wino3_pro<1, 8, 8>(ctx, p, s);
+        case 71: return launch_wino3_pro<4, 4, 4>(ctx, p, s);
         case 64: return launch_wino_pro<1, 8, 8, 8>(ctx, p, s);
         case 65: return launch_wino_pro<4, 4, 4, 8>(ctx, p, s);
         case 66: return launch_wino_pro<1, 8, 8, 16>(ctx, p, s);
