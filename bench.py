@@ -174,23 +174,35 @@ def main():
         ops.profile_enable(dev, False)
         c3 = prof["conv3x3"]
         sec = c3["ms"] * 1e-3
-        tflops = c3["flops"] / sec / 1e12
+        tflops = c3["flops"] / sec / 1e12                    # algorithmic: 2*MAC of the direct convolution
+        tflops_exec = c3["flops_executed"] / sec / 1e12      # issued to the matrix pipe (Winograd launches need 16/36)
         gbps = c3["bytes"] / sec / 1e9
+        traffic = None                                       # HBM bytes per launch from the committed PMC passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")) as f:
+                traffic = json.load(f)["_conv3x3_all"]["hbm_MB_per_launch"] * 1e6
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
-            "kernel": "conv_mfma_kernel<3x3> (all 52 conv3x3 launches per step)",
+            "kernel": "conv3x3 (52 launches per step: conv_winograd_kernel F(2x2,3x3) + conv_mfma_kernel for 8x8 / stride 2"
+                      " + conv3x3_smallcout_kernel), fp32 on v_mfma_f32_32x32x2_f32",
             "bound": "mfma",
             "achieved": tflops,
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": tflops / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "achieved_is": "algorithmic FLOPs (2*MAC of the direct form) / measured launch time",
+            "executed_TFLOPs": tflops_exec,
+            "executed_frac": tflops_exec / PEAK_FP32_MFMA_TFLOPS,
             "avg_launch_us": c3["ms"] * 1e3 / max(1, c3["launches"]),
             "launches": c3["launches"],
+            "algorithmic_bytes_per_launch": c3["bytes"] / max(1, c3["launches"]),
             "algorithmic_GBps": gbps,
             "hbm_frac": gbps / PEAK_HBM_GBPS,
             "per_step_ms": {k: v["ms"] / n_prof for k, v in prof.items()},
         }
-        log(f"conv3x3: {tflops:.1f} TFLOP/s over {c3['launches']} launches")
+        log(f"conv3x3: {tflops:.1f} algorithmic / {tflops_exec:.1f} executed TFLOP/s over {c3['launches']} launches")
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(sd)
             log(f"cpu baseline: {cpu['value']:.5f} images/sec on {cpu['cores']} threads")

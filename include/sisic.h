@@ -198,8 +198,10 @@ int sisic_mask_patches(sisic_ctx*, const float* image, const uint8_t* masks, flo
  * accumulated per class; reading synchronises the stream.                           */
 int sisic_profile_enable(sisic_ctx*, int on);
 /* kind: 0 = conv3x3, 1 = conv1x1, 2 = groupnorm stats, 3 = attention, 4 = ddpm step,
- *       5 = other.  Returns accumulated milliseconds, launches, algorithmic bytes, flops. */
-int sisic_profile_read(sisic_ctx*, int kind, double* ms, int64_t* launches, double* bytes, double* flops);
+ *       5 = other.  Returns accumulated milliseconds, launches, algorithmic bytes, algorithmic flops (2*MAC of the
+ *       direct form) and the flops actually issued to the matrix pipe (fewer for Winograd launches).  */
+int sisic_profile_read(sisic_ctx*, int kind, double* ms, int64_t* launches, double* bytes, double* flops,
+                       double* flops_executed);
 int sisic_profile_reset(sisic_ctx*);
 
 #ifdef __cplusplus

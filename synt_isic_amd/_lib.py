@@ -93,7 +93,7 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_void_p]),
     "sisic_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "sisic_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), c_int64_p, C.POINTER(C.c_double),
-                                     C.POINTER(C.c_double)]),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sisic_profile_reset": (C.c_int, [C.c_void_p]),
 }
 

@@ -29,7 +29,8 @@ static hipEvent_t take_event(sisic_ctx* ctx) {
     return e;
 }
 
-ProfileScope::ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops) : ctx(c), stream(s) {
+ProfileScope::ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops, double flops_exec)
+    : ctx(c), stream(s) {
     if (!c || !c->profiling) return;
     ev.start = take_event(c);
     ev.stop = take_event(c);
@@ -37,6 +38,7 @@ ProfileScope::ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, 
     if (!ev.start || !ev.stop) return;
     c->prof[kind].bytes += bytes;
     c->prof[kind].flops += flops;
+    c->prof[kind].flops_exec += (flops_exec < 0.0) ? flops : flops_exec;
     c->prof[kind].launches += 1;
     (void)hipEventRecord(ev.start, s);
     active = true;
@@ -155,13 +157,15 @@ int sisic_profile_enable(sisic_ctx* ctx, int on) {
     return SISIC_OK;
 }
 
-int sisic_profile_read(sisic_ctx* ctx, int kind, double* ms, int64_t* launches, double* bytes, double* flops) {
+int sisic_profile_read(sisic_ctx* ctx, int kind, double* ms, int64_t* launches, double* bytes, double* flops,
+                       double* flops_executed) {
     SISIC_REQUIRE(ctx && kind >= 0 && kind < PK_COUNT, "profile_read: bad arguments");
     SISIC_TRY(profile_collect(ctx));
     if (ms) *ms = ctx->prof[kind].ms;
     if (launches) *launches = ctx->prof[kind].launches;
     if (bytes) *bytes = ctx->prof[kind].bytes;
     if (flops) *flops = ctx->prof[kind].flops;
+    if (flops_executed) *flops_executed = ctx->prof[kind].flops_exec;
     return SISIC_OK;
 }
 

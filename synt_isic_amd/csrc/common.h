@@ -42,7 +42,7 @@ void set_error(const char* fmt, ...);
 enum ProfileKind { PK_CONV3 = 0, PK_CONV1 = 1, PK_GN = 2, PK_ATTN = 3, PK_DDPM = 4, PK_OTHER = 5, PK_COUNT = 6 };
 
 struct ProfileSlot {
-    double ms = 0, bytes = 0, flops = 0;
+    double ms = 0, bytes = 0, flops = 0, flops_exec = 0;   // flops: algorithmic (2*MAC of the direct form); flops_exec: issued to the matrix pipe
     int64_t launches = 0;
 };
 
@@ -70,7 +70,7 @@ struct ProfileScope {
     hipStream_t stream;
     PendingEvent ev{};
     bool active = false;
-    ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops);
+    ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops, double flops_exec = -1.0);
     ~ProfileScope();
 };
 
@@ -82,7 +82,7 @@ inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // conv weight packing geometry (must match conv_mfma.hip)
 constexpr int CONV_CO_TILE = 64;
-inline int conv_ci_chunk(int ksize) { return ksize == 1 ? 16 : (ksize == 3 ? 8 : 4); }
+inline int conv_ci_chunk(int ksize) { return ksize == 1 ? 32 : (ksize == 3 ? 8 : 4); }   // channel padding of the packed weights (1x1: tiles use 16 or 32)
 inline int conv_cin_pad(int cin, int ksize) { return round_up(cin, conv_ci_chunk(ksize)); }
 inline int conv_cout_pad(int cout) { return round_up(cout, CONV_CO_TILE); }
 

@@ -379,18 +379,18 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
     const double bytes = 4.0 * (double(a.B) * Cin * a.Hin * a.Win + out_elems) + 4.0 * (Cin * a.Cout * kk + a.Cout) +
                          (a.residual ? 4.0 * out_elems : 0.0);
     const double flops = 2.0 * out_elems * Cin * kk;
-    ProfileScope prof(ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops);
-
     int cfg = a.tile_cfg;
+    const bool wino_ok = a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4;
+    const bool wino_fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;   // per-thread offsets are 32-bit
+    const bool use_wino = wino_ok && ((cfg >= 60 && cfg <= 71) || (cfg == 0 && p.Hout >= 12 && p.Wout >= 12 && wino_fits32));
+    // F(2x2,3x3): 16 multiplies per 2x2 outputs and channel pair instead of 36
+    ProfileScope prof(ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops, use_wino ? flops * 16.0 / 36.0 : flops);
+
     if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50))
         return launch_conv_smallcout(ctx, a, s);      // conv_out: vector-ALU kernel, conv_small.hip
-    if (a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr) {
-        // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs.  Auto: from 12x12 output up (64 tiles of one image fill a
-        // workgroup); the 8x8 level stays on the direct kernel (too few workgroups of 4 images x 64 channels).
-        if (cfg >= 60 && cfg <= 71) return launch_conv_winograd(ctx, a, a.w_winograd, cfg, s);
-        const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;   // per-thread offsets are 32-bit
-        if (cfg == 0 && p.Hout >= 12 && p.Wout >= 12 && fits32) return launch_conv_winograd(ctx, a, a.w_winograd, 66, s);
-    }
+    // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs.  Auto: from 12x12 output up (64 tiles of one image fill a
+    // workgroup); the 8x8 level stays on the direct kernel (too few workgroups of 4 images x 64 channels).
+    if (use_wino) return launch_conv_winograd(ctx, a, a.w_winograd, cfg == 0 ? 66 : cfg, s);
     SISIC_REQUIRE(cfg < 60 || cfg > 71, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
@@ -406,11 +406,15 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
         // 1x1: the image is a flat row of H*W pixels
         p.Hin = 1; p.Win = a.Hin * a.Win; p.Hc = 1; p.Wc = p.Win; p.Hout = 1; p.Wout = p.Win; p.ups = 0;
         SISIC_REQUIRE(!a.upsample, "conv2d: 1x1 with upsample");
-        if (cfg == 0) cfg = (p.Wout <= 64) ? 22 : 23;       // measured (tools/conv_bench.py, B=64)
+        if (cfg == 0) cfg = (p.Wout <= 64) ? 22 : (p.Wout <= 256 ? 25 : 24);   // measured (tools/conv_bench.py, B=64)
         switch (cfg) {
             case 21: return launch_cfg<1, 1, 2, 2, 1, 4, 256, 16>(ctx, p, s);
             case 22: return launch_cfg<1, 1, 1, 1, 2, 2, 64, 16>(ctx, p, s);
             case 23: return launch_cfg<1, 1, 2, 1, 1, 4, 128, 16>(ctx, p, s);
+            case 24: return launch_cfg<1, 1, 1, 2, 2, 4, 256, 32, 4>(ctx, p, s);
+            case 25: return launch_cfg<1, 1, 1, 1, 2, 4, 128, 32, 4>(ctx, p, s);
+            case 26: return launch_cfg<1, 1, 1, 2, 2, 4, 256, 16, 4>(ctx, p, s);
+            case 27: return launch_cfg<1, 1, 1, 1, 2, 4, 128, 16, 4>(ctx, p, s);
         }
     } else if (a.stride == 1) {
         if (cfg == 0) cfg = p.Wout >= 24 ? 8 : (p.Wout >= 12 ? 9 : 4);   // measured (tools/conv_bench.py, B=64)

@@ -152,12 +152,14 @@ def profile_reset(device) -> None:
 
 
 def profile_read(device) -> dict:
-    """{kind: {"ms", "launches", "bytes", "flops"}} accumulated since the last reset (synchronises)."""
+    """{kind: {"ms", "launches", "bytes", "flops", "flops_executed"}} accumulated since the last reset."""
     lib = _lib.load()
     out = {}
     for name, kind in _KINDS.items():
-        ms, by, fl = C.c_double(), C.c_double(), C.c_double()
+        ms, by, fl, fx = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         n = C.c_int64()
-        check(lib.sisic_profile_read(context(device), kind, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)))
-        out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value, "flops": fl.value}
+        check(lib.sisic_profile_read(context(device), kind, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl),
+                                     C.byref(fx)))
+        out[name] = {"ms": ms.value, "launches": n.value, "bytes": by.value, "flops": fl.value,
+                     "flops_executed": fx.value}
     return out

@@ -242,7 +242,8 @@ def test_conv3x3_stride2(cfg, H, W):
 
 
 @pytest.mark.parametrize("cfg,H,W", [(0, 16, 16), (0, 8, 8), (21, 16, 16), (21, 9, 7), (22, 8, 8), (22, 5, 5),
-                                     (23, 16, 16), (23, 12, 20)])
+                                     (23, 16, 16), (23, 12, 20), (24, 16, 16), (24, 9, 7), (25, 16, 16), (25, 12, 20),
+                                     (26, 32, 32), (27, 8, 8)])
 def test_conv1x1(cfg, H, W):
     B, c0, c1, cout = 2, 40, 24, 96
     x, x2 = _rand(B, c0, H, W, seed=22), _rand(B, c1, H, W, seed=23)

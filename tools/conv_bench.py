@@ -55,7 +55,7 @@ def cfgs_for(k, stride, which):
     if which != "all":
         return [int(c) for c in which.split(",")]
     if k == 1:
-        return [0, 21, 22, 23]
+        return [0, 22, 23, 24, 25, 26, 27]
     if stride == 2:
         return [0, 11, 12, 13]
     return [60, 62, 0]
