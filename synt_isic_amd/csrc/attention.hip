@@ -10,7 +10,7 @@
 //   * S^T = K^T Q on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32, 4 k-steps for d=8), computed
 //     "swapped" so the query sits on the lane and its keys in the 16 accumulator registers:
 //     the softmax row reduction is register-local plus one cross-half shuffle;
-//   * softmax in fp32, online across key blocks (exact two-pass inside a block);
+//   * softmax in fp32, online (running max / sum / output) across 32-key tiles and key blocks;
 //   * P.V on the vector ALU: with d=8 the MFMA tile would be 3/4 padding, while the keys a lane
 //     holds in registers 4q..4q+3 are 4 consecutive V columns = one broadcast ds_read_b128.
 //
@@ -70,66 +70,51 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
         if (!wave_active) continue;
         const int nk = min(ATT_KB, N - kb0);
 
-        // pass 1: block maximum.  S^T tiles are recomputed in pass 2 instead of being kept: the MFMA
-        // pipe is otherwise idle here and 16 live accumulator registers instead of 128 keep occupancy up.
-        float mloc = -INFINITY;
+        // One pass per 32-key tile with an online softmax (running maximum m_run, running sum l_part, running
+        // output o[]): S^T tile on the MFMA pipe, tile maximum, rescale of the running state when the maximum
+        // grows, p = exp(s - m), row sum and P.V.  (A two-pass form that recomputed S^T spent twice the matrix
+        // work for the same result; on this chip matrix and vector instructions of one SIMD do not overlap.)
 #pragma unroll 1
         for (int kt = 0; kt < ATT_KT; ++kt) {
-            if (kt * 32 < nk) {
-                f32x16 S;
+            if (kt * 32 >= nk) break;
+            f32x16 S;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) S[r] = 0.0f;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
-                }
+            for (int s = 0; s < 4; ++s) {
+                const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
+                S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
+            }
+            float tmax = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (key < nk) mloc = fmaxf(mloc, S[r] * scale);
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                S[r] = (key < nk) ? S[r] * scale : -INFINITY;
+                tmax = fmaxf(tmax, S[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __expf(m_run - m_new);     // first tile: exp(-inf) = 0; unchanged maximum: 1
+            l_part *= alpha;
+#pragma unroll
+            for (int d = 0; d < ATT_D; ++d) o[d] *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float pv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pv[i] = __expf(S[4 * rq + i] - m_new);   // masked keys: exp(-inf) = 0
+                l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                const int koff = kt * 32 + 8 * rq + 4 * half;
+#pragma unroll
+                for (int d = 0; d < ATT_D; ++d) {
+                    const float4 v = *reinterpret_cast<const float4*>(&Vs[d * ATT_KB + koff]);
+                    o[d] += (pv[0] * v.x + pv[1] * v.y) + (pv[2] * v.z + pv[3] * v.w);
                 }
             }
         }
-        const float m_blk = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, m_blk);
-        const float alpha = __expf(m_run - m_new);     // first block: exp(-inf) = 0
-        l_part *= alpha;
-#pragma unroll
-        for (int d = 0; d < ATT_D; ++d) o[d] *= alpha;
-
-        // pass 2: p = exp(s - m), row sum and P.V
-#pragma unroll 1
-        for (int kt = 0; kt < ATT_KT; ++kt) {
-            if (kt * 32 < nk) {
-                f32x16 S;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
-                }
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    float pv[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int key = kt * 32 + 8 * rq + 4 * half + i;
-                        pv[i] = (key < nk) ? __expf(S[4 * rq + i] * scale - m_new) : 0.0f;
-                    }
-                    l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-                    const int koff = kt * 32 + 8 * rq + 4 * half;
-#pragma unroll
-                    for (int d = 0; d < ATT_D; ++d) {
-                        const float4 v = *reinterpret_cast<const float4*>(&Vs[d * ATT_KB + koff]);
-                        o[d] += (pv[0] * v.x + pv[1] * v.y) + (pv[2] * v.z + pv[3] * v.w);
-                    }
-                }
-            }
-        }
-        m_run = m_new;
     }
+
 
     if (wave_active) {
         const float l_tot = l_part + __shfl_xor(l_part, 32, 64);

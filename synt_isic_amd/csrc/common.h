@@ -82,7 +82,7 @@ inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // conv weight packing geometry (must match conv_mfma.hip)
 constexpr int CONV_CO_TILE = 64;
-inline int conv_ci_chunk(int ksize) { return ksize == 1 ? 32 : (ksize == 3 ? 8 : 4); }   // channel padding of the packed weights (1x1: tiles use 16 or 32)
+inline int conv_ci_chunk(int ksize) { return ksize == 1 ? 32 : (ksize == 3 ? 16 : 4); }   // channel padding of the packed weights (1x1: tiles use 16 or 32)
 inline int conv_cin_pad(int cin, int ksize) { return round_up(cin, conv_ci_chunk(ksize)); }
 inline int conv_cout_pad(int cout) { return round_up(cout, CONV_CO_TILE); }
 

@@ -51,9 +51,9 @@ struct ConvParams {
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }   // v_rcp_f32, not the IEEE division sequence
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC, int KSP = 1>
 struct ConvGeom {
-    static constexpr int NWAVES = WM * WN;
+    static constexpr int NWAVES = WM * WN * KSP;              // KSP > 1: wave groups split the channel pairs of a chunk
     static constexpr int NTHR = 64 * NWAVES;
     static constexpr int CO_TILE = WM * MT * 32;
     static constexpr int PIX = WN * NT * 32;
@@ -74,12 +74,12 @@ struct ConvGeom {
     static_assert(CO_TILE == CONV_CO_TILE, "weight packing assumes 64-channel tiles");
     static_assert(PIX % TW == 0, "tile must be whole rows");
     static_assert(NTHR % CIC == 0, "staging split");
-    static_assert(CIC % 2 == 0, "two channels per MFMA");
+    static_assert(CIC % (2 * KSP) == 0, "two channels per MFMA, whole pairs per K group");
 };
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC, int OCC>
-__global__ void __launch_bounds__(64 * WM * WN, OCC) conv_mfma_kernel(const ConvParams p) {
-    using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC, int OCC, int KSP>
+__global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(const ConvParams p) {
+    using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC, KSP>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const in_lds = smem;                    // [2][IN_BUF]
     float* const w_lds = smem + 2 * G::IN_BUF;     // [2][W_BUF]
@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_mfma_kernel(const Conv
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int kg = wave / (WM * WN), wq = wave % (WM * WN);   // K-split group, position inside the output tile
+    const int wm = wq / WN, wn = wq % WN;
     const int half = lane >> 5, l31 = lane & 31;
 
     // ---- input staging plan (invariant over the channel loop)
@@ -206,7 +207,7 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_mfma_kernel(const Conv
         const float* A = w_lds + buf * G::W_BUF + a_base;
         const float* Bm = in_lds + buf * G::IN_BUF + b_base;
 #pragma unroll
-        for (int cp = 0; cp < CIC / 2; ++cp) {
+        for (int cp = kg * (CIC / 2 / KSP); cp < (kg + 1) * (CIC / 2 / KSP); ++cp) {
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
@@ -239,6 +240,30 @@ __global__ void __launch_bounds__(64 * WM * WN, OCC) conv_mfma_kernel(const Conv
         compute_chunk(buf);
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
+    }
+
+    // ---- K-split: the wave groups hold partial sums over disjoint channel pairs of the same output tile; groups
+    // 1.. hand their accumulators to group 0 through LDS (the staging buffers are dead after the loop's last barrier).
+    if constexpr (KSP > 1) {
+        static_assert(KSP == 2, "two K groups");
+        static_assert((size_t)WM * WN * MT * NT * 16 * 64 * sizeof(float) <= G::LDS_BYTES, "reduction slab fits the staging LDS");
+        float* red = smem + (size_t)wq * MT * NT * 16 * 64 + lane;
+        if (kg == 1) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((m * NT + n) * 16 + r) * 64] = acc[m][n][r];
+        }
+        __syncthreads();
+        if (kg != 0) return;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] += red[((m * NT + n) * 16 + r) * 64];
     }
 
     // ---- epilogue: bias + per-sample channel bias (time embedding) + residual, NCHW store.
@@ -311,9 +336,9 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
     }
 }
 
-template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC, int OCC = 2>
+template <int KS, int STRIDE, int MT, int NT, int WM, int WN, int TW, int CIC, int OCC = 2, int KSP = 1>
 static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
-    using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC>;
+    using G = ConvGeom<KS, STRIDE, MT, NT, WM, WN, TW, CIC, KSP>;
     p.tiles_x = cdiv(p.Wout, TW);
     p.tiles_y = cdiv(p.Hout, G::TH);
     p.n_co_tiles = p.cout_pad / G::CO_TILE;
@@ -321,7 +346,7 @@ static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
     const int64_t nwg = (int64_t)p.B * p.tiles_x * p.tiles_y * p.n_co_tiles;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d: grid of %lld workgroups unsupported", (long long)nwg);
     p.nwg = (int)nwg;
-    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC, OCC>;
+    auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC, OCC, KSP>;
     static bool attr_set = false;
     if (!attr_set) {
         SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -347,6 +372,7 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 //   3x3 s1:  1: 2,2,1,4,TW64   2: 2,2,1,4,TW32   3: 2,2,1,4,TW16   4: 1,1,2,2,TW8   5: 2,1,1,4,TW16 (PIX128)
 //            6: 2,1,1,4,TW64   7: 2,1,1,4,TW32 (PIX128)   8: 1,2,2,4,TW32   9: 1,2,2,4,TW16 (8 waves, PIX256)
 //           14: 1,1,2,4,TW16  15: 1,1,2,4,TW8 (8 waves, PIX128)   50: vector-ALU kernel for Cout <= 4
+//           16 / 17: cfg 4's 64x64 tile with two K-split wave groups (8 waves), 16- / 8-channel chunks
 //   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
 //   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
 //   1x1 s2: 31: 2,1,1,4,TW32  32: 2,1,1,4,TW16  33: 1,1,2,2,TW8      7x7 s2: 41: 2,1,1,4,TW32 (CIC 4)
@@ -417,12 +443,14 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
             case 27: return launch_cfg<1, 1, 1, 1, 2, 4, 128, 16, 4>(ctx, p, s);
         }
     } else if (a.stride == 1) {
-        if (cfg == 0) cfg = p.Wout >= 24 ? 8 : (p.Wout >= 12 ? 9 : 4);   // measured (tools/conv_bench.py, B=64)
+        if (cfg == 0) cfg = p.Wout >= 24 ? 8 : (p.Wout >= 12 ? 9 : 16);   // measured (tools/conv_bench.py, B=64)
         switch (cfg) {
             case 1: return launch_cfg<3, 1, 2, 2, 1, 4, 64, 8>(ctx, p, s);
             case 2: return launch_cfg<3, 1, 2, 2, 1, 4, 32, 8>(ctx, p, s);
             case 3: return launch_cfg<3, 1, 2, 2, 1, 4, 16, 8>(ctx, p, s);
             case 4: return launch_cfg<3, 1, 1, 1, 2, 2, 8, 8>(ctx, p, s);
+            case 16: return launch_cfg<3, 1, 1, 1, 2, 2, 8, 16, 2, 2>(ctx, p, s);   // 8 waves: 2 K groups x (2x2), 16-channel chunks
+            case 17: return launch_cfg<3, 1, 1, 1, 2, 2, 8, 8, 2, 2>(ctx, p, s);
             case 5: return launch_cfg<3, 1, 2, 1, 1, 4, 16, 8>(ctx, p, s);
             case 6: return launch_cfg<3, 1, 2, 1, 1, 4, 64, 8>(ctx, p, s);
             case 7: return launch_cfg<3, 1, 2, 1, 1, 4, 32, 8>(ctx, p, s);

@@ -41,7 +41,7 @@ def test_abi_version_and_error_channel(lib):
     rc = lib.sisic_create(0, None)
     assert rc == -1
     assert b"sisic_create" in lib.sisic_last_error()
-    assert lib.sisic_conv_packed_numel(64, 3, 3) == 8 * 9 * 64
+    assert lib.sisic_conv_packed_numel(64, 3, 3) == 16 * 9 * 64
     assert lib.sisic_conv_packed_numel(3, 64, 3) == 64 * 9 * 64
     assert lib.sisic_conv_packed_numel(768, 256, 1) == 256 * 768
     assert lib.sisic_conv_packed_numel(64, 64, 5) == -1

@@ -67,7 +67,8 @@ def _run_conv(x, w, cfg, **kw):
 # (cfg, H, W) -- natural shapes for each tile configuration plus ragged ones that exercise the masks
 CONV3_S1 = [(1, 64, 64), (1, 12, 70), (2, 32, 32), (2, 20, 40), (3, 16, 16), (3, 24, 24), (4, 8, 8), (4, 9, 5),
             (5, 16, 16), (6, 64, 64), (6, 10, 70), (7, 32, 32), (7, 9, 40), (8, 32, 32), (8, 20, 40), (9, 16, 16),
-            (9, 24, 20), (14, 16, 16), (14, 20, 12), (15, 8, 8), (15, 16, 24), (0, 64, 64), (0, 8, 8)]
+            (9, 24, 20), (14, 16, 16), (14, 20, 12), (15, 8, 8), (15, 16, 24), (16, 8, 8), (16, 9, 5), (17, 8, 8), (17, 12, 7),
+            (0, 64, 64), (0, 8, 8)]
 
 
 @pytest.mark.parametrize("cfg,H,W", CONV3_S1)
@@ -83,7 +84,7 @@ def test_conv3x3_channel_edges(cin, cout):
     x = _rand(2, cin, 16, 32, seed=4)
     w = _rand(cout, cin, 3, 3, seed=5, scale=0.1)
     b = _rand(cout, seed=6)
-    for cfg in (0, 1, 4, 14):
+    for cfg in (0, 1, 4, 14, 16):
         _close(_run_conv(x, w, cfg, bias=b), _conv_ref(x, w, b), what=f"conv3x3 {cin}->{cout} cfg{cfg}")
 
 
@@ -128,7 +129,7 @@ def test_conv3x3_no_bias_and_identity_weight():
 
 
 @pytest.mark.parametrize("cfg,H,W", [(1, 64, 64), (2, 32, 32), (3, 16, 16), (4, 8, 8), (2, 20, 24), (5, 16, 16),
-                                     (6, 64, 64), (7, 32, 32), (8, 32, 32), (9, 16, 16)])
+                                     (6, 64, 64), (7, 32, 32), (8, 32, 32), (9, 16, 16), (16, 8, 8), (17, 8, 8)])
 def test_conv3x3_fused_everything(cfg, H, W):
     """two sources whose seam falls inside a channel chunk + GN/SiLU prologue + time bias + residual."""
     B, c0, c1, cout = 2, 20, 12, 64

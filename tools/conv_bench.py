@@ -58,7 +58,7 @@ def cfgs_for(k, stride, which):
         return [0, 22, 23, 24, 25, 26, 27]
     if stride == 2:
         return [0, 11, 12, 13]
-    return [60, 62, 0]
+    return [4, 16, 17, 66, 0]
 
 
 def main():
