@@ -377,8 +377,38 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         __syncthreads();
     }
 
-    // ---- output transform: four rounds of 16 output channels through LDS
+    // ---- output transform: four rounds of 16 output channels through LDS.  Bias, time-embedding and
+    // residual operands of all four rounds are fetched up front so their latency is paid once, under
+    // the first round's LDS traffic, rather than once per round behind a barrier.
     const size_t HWout = (size_t)p.Hc * p.Wc;
+    constexpr int EK = 1024 / G::THREADS;
+    const int et = tid & 63;                                   // tile of this thread (same in every round)
+    const int eimg = et / (TY * TX), ety = (et / TX) % TY, etx = et % TX;
+    const int eb = b0 + eimg, eoy = oy0 + 2 * ety, eox = ox0 + 2 * etx;
+    const int ebc = min(eb, p.B - 1);
+    int eoff[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) eoff[i][j] = min(eoy + i, p.Hc - 1) * p.Wc + min(eox + j, p.Wc - 1);
+    float eadd[4][EK], eres[4][EK][2][2];
+#pragma unroll
+    for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            const int co = co0 + (q >> 1) * 32 + 16 * (q & 1) + ((tid + k * G::THREADS) >> 6);
+            const int coc = min(co, p.Cout - 1);
+            float add = 0.0f;
+            if (p.bias) add += p.bias[coc];
+            if (p.chan_bias) add += p.chan_bias[(size_t)ebc * p.chan_bias_stride + coc];
+            eadd[q][k] = add;
+            const size_t plane = ((size_t)ebc * p.Cout + coc) * HWout;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) eres[q][k][i][j] = p.residual ? p.residual[plane + eoff[i][j]] : 0.0f;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
         const int mt = q >> 1, rbase = 8 * (q & 1);
@@ -396,12 +426,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 1024 / G::THREADS; ++k) {
-            const int pi = tid + k * G::THREADS;       // 1024 (channel, tile) pairs
-            const int co16 = pi >> 6, t = pi & 63;
+        for (int k = 0; k < EK; ++k) {
+            const int co16 = (tid + k * G::THREADS) >> 6;       // 1024 (channel, tile) pairs per round
             float m[4][4];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = M_lds[(xi * 16 + co16) * 64 + t];
+            for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = M_lds[(xi * 16 + co16) * 64 + et];
             float s[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -415,37 +444,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
                 y[i][1] = s[i][1] - s[i][2] - s[i][3];
             }
             const int co = co0 + mt * 32 + 16 * (q & 1) + co16;
-            const int img = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
-            const int b = b0 + img;
-            const int oy = oy0 + 2 * ty, ox = ox0 + 2 * tx;
-            const bool ok = co < p.Cout && b < p.B;
-            const int coc = min(co, p.Cout - 1), bc = min(b, p.B - 1);
-            float add = 0.0f;
-            if (p.bias) add += p.bias[coc];
-            if (p.chan_bias) add += p.chan_bias[(size_t)bc * p.chan_bias_stride + coc];
-            const size_t plane = ((size_t)bc * p.Cout + coc) * HWout;
-            size_t idx[2][2];
-            float res[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    idx[i][j] = plane + (size_t)min(oy + i, p.Hc - 1) * p.Wc + min(ox + j, p.Wc - 1);
-                    res[i][j] = 0.0f;
-                }
-            if (p.residual) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) res[i][j] = p.residual[idx[i][j]];
-            }
+            const bool ok = co < p.Cout && eb < p.B;
+            const size_t plane = ((size_t)ebc * p.Cout + min(co, p.Cout - 1)) * HWout;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float v = y[i][j] + add + res[i][j];
+                    float v = y[i][j] + eadd[q][k] + eres[q][k][i][j];
                     if (p.relu) v = fmaxf(v, 0.0f);
-                    if (ok && oy + i < p.Hc && ox + j < p.Wc) p.out[idx[i][j]] = v;
+                    if (ok && eoy + i < p.Hc && eox + j < p.Wc) p.out[plane + eoff[i][j]] = v;
                 }
             }
         }

@@ -60,7 +60,20 @@ gn_stats_kernel(const float* __restrict__ in0, int c0, const float* __restrict__
         const float* src = plane(g * cpg + j);
         if (vec) {
             const float4* s4 = reinterpret_cast<const float4*>(src);
-            for (int i = tid; i < HW / 4; i += GN_THREADS) {
+            const int n4 = HW / 4;
+            int i = tid;
+            // four independent 16-byte loads in flight per thread: the kernel is latency/bandwidth-bound
+            for (; i + 3 * GN_THREADS < n4; i += 4 * GN_THREADS) {
+                const float4 v0 = s4[i], v1 = s4[i + GN_THREADS], v2 = s4[i + 2 * GN_THREADS], v3 = s4[i + 3 * GN_THREADS];
+                const float4 vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float a = vv[u].x - K, bq = vv[u].y - K, c = vv[u].z - K, d = vv[u].w - K;
+                    s1 += (a + bq) + (c + d);
+                    s2 += (a * a + bq * bq) + (c * c + d * d);
+                }
+            }
+            for (; i < n4; i += GN_THREADS) {
                 const float4 v = s4[i];
                 const float a = v.x - K, bq = v.y - K, c = v.z - K, d = v.w - K;
                 s1 += (a + bq) + (c + d);
