@@ -82,7 +82,16 @@ typedef struct sisic_conv_args {
     int tile_cfg;           /* 0 = auto; >0 forces a tile configuration (tests/tuning) */
     const float* w_winograd; /* dev, layout of sisic_conv_winograd_pack, or NULL: when given, 3x3 stride-1
                                 convolutions may run as Winograd F(2x2,3x3) (tile_cfg 60/61 force it)        */
+    float* stats_out;        /* dev [B,Cout,slots,4] or NULL: each workgroup also writes (count, sum, sum of squared
+                                deviations from its own mean, 0) of the values it stored, per image and channel, so that the GroupNorm
+                                that follows needs sisic_groupnorm_finalize only (no second pass over `out`).
+                                slots = sisic_conv_stats_slots(args); 0 there means "not available for this
+                                launch" and stats_out must stay NULL                                          */
 } sisic_conv_args;
+
+/* Number of partial-statistics slots per (image, output channel) that sisic_conv2d(args) writes to
+ * args->stats_out, or 0 when the kernel selected for these arguments does not produce them.      */
+int sisic_conv_stats_slots(const sisic_conv_args* args);
 
 /* Winograd-domain filters U = G g G^T of an OIHW 3x3 weight, computed in float64:
  * number of floats, and dev OIHW -> dev packed [Cin_pad][16][Cout_pad].                      */
@@ -105,6 +114,16 @@ int sisic_groupnorm_stats(sisic_ctx*, const float* in0, int c0, const float* in1
                           int B, int HW, int groups, float eps,
                           const float* gamma, const float* beta,
                           float* scale, float* shift, void* stream);
+
+/* GroupNorm statistics from convolution-epilogue partials (sisic_conv_args.stats_out) instead of a pass
+ * over the tensor: same outputs as sisic_groupnorm_stats for the concatenation of two producers'
+ * outputs (stats1 NULL / c1 = 0 for one).  The partials are merged in float64 (sum of M2_i + n_i (mean_i - mean)^2) in a fixed order.
+ * HW is accepted for symmetry with sisic_groupnorm_stats; the element counts travel with the partials.   */
+int sisic_groupnorm_finalize(sisic_ctx*, const float* stats0, int c0, int slots0,
+                             const float* stats1, int c1, int slots1,
+                             int B, int HW, int groups, float eps,
+                             const float* gamma, const float* beta,
+                             float* scale, float* shift, void* stream);
 
 /* Multi-head self-attention core (replaces scaled_dot_product_attention inside
  * diffusers' Attention, heads = C/head_dim, softmax in fp32, scale head_dim^-0.5).

@@ -37,6 +37,7 @@ class ConvArgs(C.Structure):
         ("residual", C.c_void_p), ("relu", C.c_int),
         ("out", C.c_void_p), ("tile_cfg", C.c_int),
         ("w_winograd", C.c_void_p),
+        ("stats_out", C.c_void_p),
     ]
 
 
@@ -63,6 +64,10 @@ SIGNATURES = {
     "sisic_conv_winograd_numel": (C.c_int64, [C.c_int, C.c_int]),
     "sisic_conv_winograd_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sisic_conv2d": (C.c_int, [C.c_void_p, C.POINTER(ConvArgs), C.c_void_p]),
+    "sisic_conv_stats_slots": (C.c_int, [C.POINTER(ConvArgs)]),
+    "sisic_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
     "sisic_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),

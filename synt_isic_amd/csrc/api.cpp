@@ -125,6 +125,16 @@ int sisic_conv2d(sisic_ctx* ctx, const sisic_conv_args* args, void* stream) {
     return launch_conv2d(ctx, *args, static_cast<hipStream_t>(stream));
 }
 
+int sisic_conv_stats_slots(const sisic_conv_args* args) { return args ? conv_stats_slots(*args) : 0; }
+
+int sisic_groupnorm_finalize(sisic_ctx* ctx, const float* stats0, int c0, int slots0, const float* stats1, int c1,
+                             int slots1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,
+                             float* scale, float* shift, void* stream) {
+    SISIC_REQUIRE(ctx, "groupnorm_finalize: null context");
+    return launch_gn_finalize(ctx, stats0, c0, slots0, stats1, c1, slots1, B, HW, groups, eps, gamma, beta, scale,
+                              shift, static_cast<hipStream_t>(stream));
+}
+
 int sisic_groupnorm_stats(sisic_ctx* ctx, const float* in0, int c0, const float* in1, int c1, int B, int HW,
                           int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
                           void* stream) {

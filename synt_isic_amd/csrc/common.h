@@ -90,6 +90,10 @@ inline int conv_cout_pad(int cout) { return round_up(cout, CONV_CO_TILE); }
 int launch_conv2d(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
 int launch_conv_smallcout(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
 // conv_winograd.hip: F(2x2,3x3) for 3x3 stride-1 convolutions
+int conv_stats_slots(const sisic_conv_args& a);
+int launch_gn_finalize(sisic_ctx*, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
+                       int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                       hipStream_t s);
 int launch_conv_winograd(sisic_ctx*, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s);
 int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s);
 int64_t winograd_packed_numel(int Cout, int Cin);

@@ -46,8 +46,20 @@ struct ConvParams {
     const float* residual;
     int relu;
     float* out;
+    float* stats;      // optional GroupNorm partials [B][Cout][tiles_y*tiles_x*WN][4] = (count, sum, centred M2, 0)
+    int* slots_query;  // host only: when set, launch_cfg reports the slot count of its tiling instead of launching
     int tiles_x, tiles_y, n_co_tiles, nwg, nchunks;
 };
+
+// sum over each aligned run of 32 lanes (the pixels of one accumulator row): DPP butterflies inside the two rows of 16,
+// then one cross-row exchange.  Fixed order: the GroupNorm partials are bit-reproducible.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v + __shfl_xor(v, 16);
+}
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }   // v_rcp_f32, not the IEEE division sequence
 
@@ -292,11 +304,18 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
             for (int r = 0; r < 16; ++r)
                 cbias[m][r] += cb[min(co0 + wm * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, p.Cout - 1)];
     }
+    float psum[MT][16];      // per output channel: sum of this lane's stored values (GroupNorm partials)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psum[m][r] = 0.0f;
+    unsigned pvmask = 0;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int pix = wn * NT * 32 + n * 32 + l31;
         const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
         const bool pv = oy < p.Hout && ox < p.Wout;
+        pvmask |= pv ? (1u << n) : 0u;
         const size_t pix_off = (size_t)min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -316,10 +335,39 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
                 float v = acc[m][n][r] + cbias[m][r] + res[r];
                 if (p.relu) v = fmaxf(v, 0.0f);
                 if (pv && co < p.Cout) p.out[((size_t)b * p.Cout + co) * HWout + pix_off] = v;
+                acc[m][n][r] = v;
+                psum[m][r] += pv ? v : 0.0f;
+            }
+        }
+    }
+
+    // ---- GroupNorm partials of what was just stored: per output channel and wave, (count, sum, sum of squared
+    // deviations from the wave's own mean) over the wave's NT*32 pixels; merged exactly by gn_finalize_kernel.
+    if (p.stats) {
+        const float cnt = half_wave_sum((float)__builtin_popcount(pvmask));
+        const float inv = 1.0f / fmaxf(cnt, 1.0f);
+        const int slots = p.tiles_x * p.tiles_y * WN, slot = (ty * p.tiles_x + tx) * WN + wn;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float s1 = half_wave_sum(psum[m][r]);
+                const float mean = s1 * inv;
+                float q = 0.0f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float d = acc[m][n][r] - mean;
+                    q += ((pvmask >> n) & 1u) ? d * d : 0.0f;
+                }
+                q = half_wave_sum(q);
+                if (l31 == 0 && co < p.Cout)
+                    reinterpret_cast<float4*>(p.stats)[((size_t)b * p.Cout + co) * slots + slot] = make_float4(cnt, s1, q, 0.0f);
             }
         }
     }
 }
+
 
 // OIHW -> [Cin_pad][KK][cout_pad], zero padded
 __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, int cin_pad, int cout_pad,
@@ -346,6 +394,10 @@ static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
     const int64_t nwg = (int64_t)p.B * p.tiles_x * p.tiles_y * p.n_co_tiles;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d: grid of %lld workgroups unsupported", (long long)nwg);
     p.nwg = (int)nwg;
+    if (p.slots_query) {           // sisic_conv_stats_slots(): report the partial-statistics layout, launch nothing
+        *p.slots_query = p.tiles_x * p.tiles_y * WN;
+        return SISIC_OK;
+    }
     auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC, OCC, KSP>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -376,7 +428,39 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 //   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
 //   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
 //   1x1 s2: 31: 2,1,1,4,TW32  32: 2,1,1,4,TW16  33: 1,1,2,2,TW8      7x7 s2: 41: 2,1,1,4,TW32 (CIC 4)
-int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
+// Winograd F(2x2,3x3) is taken for 3x3 stride-1 convolutions with transformed filters at hand: when forced by
+// tile_cfg 60..71, or automatically from 12x12 outputs up (per-thread load offsets there are 32-bit).
+static bool winograd_selected(const sisic_conv_args& a) {
+    if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4)) return false;
+    const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
+    const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
+    return (a.tile_cfg >= 60 && a.tile_cfg <= 71) || (a.tile_cfg == 0 && Hout >= 12 && Wout >= 12 && fits32);
+}
+
+static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s, int* slots_query);
+
+// GroupNorm partials (sisic_conv_args.stats_out): the Winograd kernels' output transform leaves one slot per
+// workgroup tile of an image (16x16 outputs, or 8x8 for the four-image tilings); the direct MFMA kernel one per
+// pixel tile and pixel-wave (the dispatch below is asked which tiling it would launch).  The third Winograd form and
+// the vector-ALU small-Cout kernel do not produce them.
+int conv_stats_slots(const sisic_conv_args& a) {
+    if (winograd_selected(a)) {
+        if (a.tile_cfg == 70 || a.tile_cfg == 71) return 0;
+        const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
+        const int cfg = a.tile_cfg == 0 ? 66 : a.tile_cfg;
+        const int edge = (cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 8 : 16;
+        return ((Hout + edge - 1) / edge) * ((Wout + edge - 1) / edge);
+    }
+    int slots = 0;
+    sisic_conv_args q = a;
+    q.stats_out = nullptr;
+    if (dispatch_conv2d(nullptr, q, nullptr, &slots) != SISIC_OK) return 0;
+    return slots;
+}
+
+int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) { return dispatch_conv2d(ctx, a, s, nullptr); }
+
+static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s, int* slots_query) {
     SISIC_REQUIRE(a.in0 && a.w_packed && a.out, "conv2d: null tensor");
     SISIC_REQUIRE(a.B > 0 && a.Hin > 0 && a.Win > 0 && a.c0 > 0 && a.c1 >= 0 && a.Cout > 0, "conv2d: bad shape");
     SISIC_REQUIRE((a.c1 == 0) == (a.in1 == nullptr), "conv2d: in1/c1 mismatch");
@@ -398,6 +482,7 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
     p.bias = a.bias; p.Cout = a.Cout;
     p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
     p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu; p.out = a.out;
+    p.stats = a.stats_out; p.slots_query = slots_query;
 
     const int Cin = a.c0 + a.c1;
     const double kk = double(a.ksize) * a.ksize;
@@ -406,17 +491,23 @@ int launch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
                          (a.residual ? 4.0 * out_elems : 0.0);
     const double flops = 2.0 * out_elems * Cin * kk;
     int cfg = a.tile_cfg;
-    const bool wino_ok = a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4;
-    const bool wino_fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;   // per-thread offsets are 32-bit
-    const bool use_wino = wino_ok && ((cfg >= 60 && cfg <= 71) || (cfg == 0 && p.Hout >= 12 && p.Wout >= 12 && wino_fits32));
+    const bool use_wino = winograd_selected(a);
     // F(2x2,3x3): 16 multiplies per 2x2 outputs and channel pair instead of 36
-    ProfileScope prof(ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops, use_wino ? flops * 16.0 / 36.0 : flops);
+    SISIC_REQUIRE(a.stats_out == nullptr || conv_stats_slots(a) > 0,
+                  "conv2d: stats_out given but sisic_conv_stats_slots() is 0 for these arguments");
+    ProfileScope prof(slots_query ? nullptr : ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops,
+                      use_wino ? flops * 16.0 / 36.0 : flops);
 
-    if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50))
+    if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50)) {
+        if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)
         return launch_conv_smallcout(ctx, a, s);      // conv_out: vector-ALU kernel, conv_small.hip
+    }
     // Winograd F(2x2,3x3): 2.25x fewer MFMA FLOPs.  Auto: from 12x12 output up (64 tiles of one image fill a
     // workgroup); the 8x8 level stays on the direct kernel (too few workgroups of 4 images x 64 channels).
-    if (use_wino) return launch_conv_winograd(ctx, a, a.w_winograd, cfg == 0 ? 66 : cfg, s);
+    if (use_wino) {
+        SISIC_REQUIRE(!slots_query, "conv2d: internal: slot query on the Winograd path");
+        return launch_conv_winograd(ctx, a, a.w_winograd, cfg == 0 ? 66 : cfg, s);
+    }
     SISIC_REQUIRE(cfg < 60 || cfg > 71, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;

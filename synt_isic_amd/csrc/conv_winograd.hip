@@ -49,6 +49,7 @@ struct WinoParams {
     const float* residual;
     int relu;
     float* out;
+    float* stats;       // optional [B][Cout][groups_y*groups_x][4]: per-workgroup (count, sum, centred M2, 0) of the stored values
     int groups_x, groups_y, groups_b, n_co_tiles, nwg, nchunks;
     int stagger;        // 1: half of the waves run MFMA-first, the other half stage-first (see the channel loop)
 };
@@ -70,6 +71,21 @@ __device__ __forceinline__ const char* uniform_ptr(const void* ptr) {
 // x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp): __fdividef expands to the 10-instruction IEEE
 // division sequence, and every VALU instruction in this loop displaces matrix work (tools/mfma_valu_probe.hip).
 __device__ __forceinline__ float wsilu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// Sum over each aligned run of 16 lanes (DPP butterflies: quad swaps, then the two row mirrors); every lane of
+// the run receives the total.  Fixed order, so the GroupNorm partials are bit-reproducible.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float wave64_sum(float v) {
+    const int r = __float_as_int(row16_sum(v));
+    return (__int_as_float(__builtin_amdgcn_readlane(r, 0)) + __int_as_float(__builtin_amdgcn_readlane(r, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(r, 32)) + __int_as_float(__builtin_amdgcn_readlane(r, 48)));
+}
 
 // NW = waves per workgroup: 8 (two transform positions xi per wave, 128 accumulator registers, 2 waves/SIMD)
 //                       or 16 (one xi per wave, 64 accumulator registers, 4 waves/SIMD).
@@ -446,13 +462,49 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             const int co = co0 + mt * 32 + 16 * (q & 1) + co16;
             const bool ok = co < p.Cout && eb < p.B;
             const size_t plane = ((size_t)ebc * p.Cout + min(co, p.Cout - 1)) * HWout;
+            float vv[2][2];
+            bool in[2][2];
+            float s1 = 0.0f, cnt = 0.0f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float v = y[i][j] + eadd[q][k] + eres[q][k][i][j];
                     if (p.relu) v = fmaxf(v, 0.0f);
-                    if (ok && eoy + i < p.Hc && eox + j < p.Wc) p.out[plane + eoff[i][j]] = v;
+                    in[i][j] = ok && eoy + i < p.Hc && eox + j < p.Wc;
+                    if (in[i][j]) {
+                        p.out[plane + eoff[i][j]] = v;
+                        s1 += v;
+                        cnt += 1.0f;
+                    }
+                    vv[i][j] = v;
+                }
+            }
+            if (p.stats) {
+                // One output channel per wave here (co16 is wave-uniform); lanes are the 64 tiles: all of one image
+                // (NIMG == 1) or 16 per image (NIMG == 4).  Per image and workgroup: (count, sum, sum of squared
+                // deviations from this tile's own mean) -- centred partials, merged exactly by gn_finalize_kernel.
+                const int slots = p.groups_x * p.groups_y, slot = gy * p.groups_x + gx;
+                if (NIMG == 1) {
+                    s1 = wave64_sum(s1);
+                    cnt = wave64_sum(cnt);
+                } else {
+                    s1 = row16_sum(s1);
+                    cnt = row16_sum(cnt);
+                }
+                const float mean_t = s1 / fmaxf(cnt, 1.0f);
+                float m2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float d = vv[i][j] - mean_t;
+                        if (in[i][j]) m2 += d * d;
+                    }
+                m2 = (NIMG == 1) ? wave64_sum(m2) : row16_sum(m2);
+                if (ok && (et % (TY * TX)) == 0) {
+                    float4* dst = reinterpret_cast<float4*>(p.stats) + ((size_t)eb * p.Cout + co) * slots + slot;
+                    *dst = make_float4(cnt, s1, m2, 0.0f);
                 }
             }
         }
@@ -550,6 +602,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
     p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu;
     p.out = a.out;
+    p.stats = a.stats_out;
     SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67 || cfg == 71) ? 4 : 1) < 4294967296.0,
                   "conv2d(winograd): per-thread load offsets are 32-bit; this tensor needs the direct kernel");
     p.stagger = (cfg >= 64 && cfg <= 67) ? 1 : 0;

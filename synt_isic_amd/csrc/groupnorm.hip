@@ -116,4 +116,90 @@ int launch_gn_stats(sisic_ctx* ctx, const float* in0, int c0, const float* in1, 
     return SISIC_OK;
 }
 
+// Finalize from per-workgroup partials (count, sum, M2 about the partial's own mean): one wave per (image, group).
+// Lanes stride over the (channel, slot) pairs of the group; the pairwise-merge identity
+//     M2 = sum_i M2_i + sum_i n_i (mean_i - mean)^2
+// is evaluated in float64 with fixed-order butterflies, so the result is independent of timing and as robust against
+// |mean| >> std as the shifted single pass of gn_stats_kernel.
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restrict__ st0, int c0, int slots0,
+                                                         const float4* __restrict__ st1, int c1, int slots1,
+                                                         int groups, float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ scale,
+                                                         float* __restrict__ shift) {
+    const int C = c0 + c1, gs = C / groups;
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int lane = threadIdx.x;
+    // the group's channels are one contiguous run of partials in each producer's buffer ([b][c][slot])
+    const int ca = g * gs, cb = ca + gs;
+    const int a0 = min(ca, c0), b0 = min(cb, c0);                 // channels [a0, b0) of the first producer
+    const int a1 = max(ca, c0) - c0, b1 = max(cb, c0) - c0;       // channels [a1, b1) of the second
+    const float4* run0 = st0 + ((size_t)b * c0 + a0) * slots0;
+    const int len0 = (b0 - a0) * slots0;
+    const float4* run1 = st1 ? st1 + ((size_t)b * c1 + a1) * slots1 : nullptr;
+    const int len1 = st1 ? (b1 - a1) * slots1 : 0;
+    constexpr int KEEP = 4;                                        // partials per lane and producer held in registers
+    float4 k0[KEEP], k1[KEEP];
+    double n = 0.0, s1 = 0.0, m2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) {
+        const int i = lane + 64 * j;
+        k0[j] = i < len0 ? run0[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        k1[j] = i < len1 ? run1[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) {
+        n += (double)k0[j].x + (double)k1[j].x;
+        s1 += (double)k0[j].y + (double)k1[j].y;
+        m2 += (double)k0[j].z + (double)k1[j].z;
+    }
+    for (int i = lane + 64 * KEEP; i < len0; i += 64) { const float4 v = run0[i]; n += v.x; s1 += v.y; m2 += v.z; }
+    for (int i = lane + 64 * KEEP; i < len1; i += 64) { const float4 v = run1[i]; n += v.x; s1 += v.y; m2 += v.z; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_xor(n, off);
+        s1 += __shfl_xor(s1, off);
+        m2 += __shfl_xor(m2, off);
+    }
+    const double mean = s1 / n;
+    double between = 0.0;
+    auto dev = [&](const float4 v) {
+        if (v.x > 0.0f) {
+            const double d = (double)v.y / (double)v.x - mean;
+            between += (double)v.x * d * d;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) { dev(k0[j]); dev(k1[j]); }
+    for (int i = lane + 64 * KEEP; i < len0; i += 64) dev(run0[i]);
+    for (int i = lane + 64 * KEEP; i < len1; i += 64) dev(run1[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) between += __shfl_xor(between, off);
+    const double var = fmax((m2 + between) / n, 0.0);
+    const float rstd = 1.0f / sqrtf((float)var + eps);
+    const float meanf = (float)mean;
+    for (int cc = lane; cc < gs; cc += 64) {
+        const int c = ca + cc;
+        const float sc = gamma[c] * rstd;
+        scale[(size_t)b * C + c] = sc;
+        shift[(size_t)b * C + c] = beta[c] - meanf * sc;
+    }
+}
+
+int launch_gn_finalize(sisic_ctx* ctx, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
+                       int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
+                       hipStream_t s) {
+    SISIC_REQUIRE(st0 && gamma && beta && scale && shift, "groupnorm_finalize: null tensor");
+    SISIC_REQUIRE((c1 == 0) == (st1 == nullptr), "groupnorm_finalize: stats1/c1 mismatch");
+    const int C = c0 + c1;
+    SISIC_REQUIRE(B > 0 && HW > 0 && groups > 0 && c0 > 0 && C % groups == 0 && slots0 > 0 && (c1 == 0 || slots1 > 0),
+                  "groupnorm_finalize: C=%d groups=%d slots=%d/%d", C, groups, slots0, slots1);
+    (void)HW;   // the element count travels with the partials
+    ProfileScope prof(ctx, s, PK_GN, 16.0 * B * (c0 * (double)slots0 + c1 * (double)slots1) + 8.0 * B * C, 0.0);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, reinterpret_cast<const float4*>(st0), c0,
+                       slots0, reinterpret_cast<const float4*>(st1), c1, slots1, groups, eps, gamma, beta, scale,
+                       shift);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
 }  // namespace sisic

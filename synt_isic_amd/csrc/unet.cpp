@@ -61,6 +61,8 @@ struct Buf {
     float* p = nullptr;
     int C = 0, H = 0, W = 0;
     int refs = 0;
+    float* stats = nullptr;   // GroupNorm partials written by the producing convolution (sisic_conv_args.stats_out)
+    int slots = 0;
 };
 
 struct PoolBlock {
@@ -118,7 +120,10 @@ struct sisic_unet {
     uint64_t stage_next = 0;
     hipEvent_t stage_ev[STAGE_SLOTS] = {};
     bool stage_used[STAGE_SLOTS] = {};
-    bool use_winograd = true;    // SISIC_WINOGRAD=0 in the environment keeps every 3x3 on the direct kernel
+    bool use_winograd = true;
+    bool fuse_gn = true;            // GroupNorm statistics from convolution epilogues where the kernel offers them
+                                    // (SISIC_FUSED_GN=0 in the environment: always the stand-alone statistics pass)
+    // SISIC_WINOGRAD=0 in the environment keeps every 3x3 on the direct kernel
     float* eps_buf = nullptr;    // sampling loop scratch [B,C,H,W]
     size_t eps_floats = 0;
 
@@ -402,16 +407,25 @@ struct Fwd {
         return bufs.back().get();
     }
     void release(Buf* b) {
-        if (b && --b->refs == 0 && b->p) { pool_put(u, b->p); b->p = nullptr; }
+        if (b && --b->refs == 0 && b->p) {
+            pool_put(u, b->p);
+            b->p = nullptr;
+            if (b->stats) { pool_put(u, b->stats); b->stats = nullptr; }
+        }
     }
 
     int gn(const Buf* x, const Buf* skip, const NormW& n) {
+        if (x->stats && (!skip || skip->stats))   // every producer left partials: no pass over the tensors
+            return launch_gn_finalize(u->ctx, x->stats, x->C, x->slots, skip ? skip->stats : nullptr, skip ? skip->C : 0,
+                                      skip ? skip->slots : 0, B, x->H * x->W, u->cfg.norm_groups, u->cfg.norm_eps,
+                                      n.gamma, n.beta, u->gn_scale, u->gn_shift, s);
         return launch_gn_stats(u->ctx, x->p, x->C, skip ? skip->p : nullptr, skip ? skip->C : 0, B, x->H * x->W,
                                u->cfg.norm_groups, u->cfg.norm_eps, n.gamma, n.beta, u->gn_scale, u->gn_shift, s);
     }
 
     int conv(const ConvW& c, const float* in0, int c0, const float* in1, int c1, int H, int W, int stride, int ups,
-             bool gn_prologue, bool silu, const float* chan_bias, const float* residual, float* out) {
+             bool gn_prologue, bool silu, const float* chan_bias, const float* residual, float* out,
+             Buf* normed_later = nullptr) {
         sisic_conv_args a{};
         a.in0 = in0; a.c0 = c0; a.in1 = in1; a.c1 = c1;
         a.B = B; a.Hin = H; a.Win = W; a.upsample = ups; a.ksize = c.k; a.stride = stride;
@@ -420,6 +434,14 @@ struct Fwd {
         if (gn_prologue) { a.gn_scale = u->gn_scale; a.gn_shift = u->gn_shift; a.gn_silu = silu ? 1 : 0; }
         a.chan_bias = chan_bias; a.chan_bias_stride = tproj_stride;
         a.residual = residual; a.out = out;
+        if (normed_later && u->fuse_gn) {          // a GroupNorm reads this output: have the epilogue leave partials
+            const int slots = conv_stats_slots(a);
+            if (slots > 0) {
+                SISIC_TRY(pool_get(u, (size_t)B * c.cout * slots * 4, &normed_later->stats));
+                normed_later->slots = slots;
+                a.stats_out = normed_later->stats;
+            }
+        }
         return launch_conv2d(u->ctx, a, s);
     }
 
@@ -432,7 +454,7 @@ struct Fwd {
         SISIC_TRY(gn(x, skip, r.norm1));
         Buf* h = make(r.cout, H, W, &rc); SISIC_TRY(rc);
         SISIC_TRY(conv(r.conv1, x->p, x->C, skip ? skip->p : nullptr, c1, H, W, 1, 0, true, true,
-                       tproj + r.temb_off, nullptr, h->p));
+                       tproj + r.temb_off, nullptr, h->p, h));
         const float* residual = x->p;
         Buf* sc = nullptr;
         if (r.shortcut.k) {
@@ -445,7 +467,7 @@ struct Fwd {
         }
         SISIC_TRY(gn(h, nullptr, r.norm2));
         Buf* o = make(r.cout, H, W, &rc); SISIC_TRY(rc);
-        SISIC_TRY(conv(r.conv2, h->p, r.cout, nullptr, 0, H, W, 1, 0, true, true, nullptr, residual, o->p));
+        SISIC_TRY(conv(r.conv2, h->p, r.cout, nullptr, 0, H, W, 1, 0, true, true, nullptr, residual, o->p, o));
         release(h);
         release(sc);
         *out = o;
@@ -464,7 +486,7 @@ struct Fwd {
         SISIC_TRY(launch_attention(u->ctx, qkv->p, o->p, B, C, N, u->cfg.head_dim, s));
         release(qkv);
         Buf* y = make(C, H, W, &rc); SISIC_TRY(rc);
-        SISIC_TRY(conv(a.out, o->p, C, nullptr, 0, H, W, 1, 0, false, false, nullptr, x->p, y->p));
+        SISIC_TRY(conv(a.out, o->p, C, nullptr, 0, H, W, 1, 0, false, false, nullptr, x->p, y->p, y));
         release(o);
         *out = y;
         return SISIC_OK;
@@ -477,7 +499,7 @@ struct Fwd {
         std::vector<Buf*> skips;
 
         Buf* x = make(u->conv_in.cout, H, W, &rc); SISIC_TRY(rc);
-        SISIC_TRY(conv(u->conv_in, sample, cfg.in_channels, nullptr, 0, H, W, 1, 0, false, false, nullptr, nullptr, x->p));
+        SISIC_TRY(conv(u->conv_in, sample, cfg.in_channels, nullptr, 0, H, W, 1, 0, false, false, nullptr, nullptr, x->p, x));
         x->refs++;                 // held by `x` and by the skip stack
         skips.push_back(x);
 
@@ -498,7 +520,7 @@ struct Fwd {
             if (i != n - 1) {
                 const int Ho = (x->H + 2 - 3) / 2 + 1, Wo = (x->W + 2 - 3) / 2 + 1;
                 Buf* y = make(u->downsamplers[i].cout, Ho, Wo, &rc); SISIC_TRY(rc);
-                SISIC_TRY(conv(u->downsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 2, 0, false, false, nullptr, nullptr, y->p));
+                SISIC_TRY(conv(u->downsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 2, 0, false, false, nullptr, nullptr, y->p, y));
                 release(x);
                 x = y;
                 x->refs++;
@@ -534,7 +556,7 @@ struct Fwd {
             }
             if (i != n - 1) {
                 Buf* y = make(u->upsamplers[i].cout, 2 * x->H, 2 * x->W, &rc); SISIC_TRY(rc);
-                SISIC_TRY(conv(u->upsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 1, 1, false, false, nullptr, nullptr, y->p));
+                SISIC_TRY(conv(u->upsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 1, 1, false, false, nullptr, nullptr, y->p, y));
                 release(x);
                 x = y;
             }
@@ -578,8 +600,10 @@ int run_forward(sisic_unet* u, const float* sample, const float* tproj, int tpro
                 int W, hipStream_t s) {
     Fwd f{u, s, B, tproj, tproj_stride, {}};
     const int rc = f.run(sample, out, H, W);
-    for (auto& b : f.bufs)
-        if (b->p) pool_put(u, b->p);   // error paths: hand everything back
+    for (auto& b : f.bufs) {           // error paths: hand everything back
+        if (b->p) pool_put(u, b->p);
+        if (b->stats) pool_put(u, b->stats);
+    }
     return rc;
 }
 
@@ -604,6 +628,7 @@ int sisic_unet_create(sisic_ctx* ctx, const sisic_unet_config* cfg, sisic_unet**
     u->cfg = *cfg;
     u->freqs.assign(cfg->freqs, cfg->freqs + cfg->n_freqs);
     if (const char* e = std::getenv("SISIC_WINOGRAD")) u->use_winograd = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SISIC_FUSED_GN")) u->fuse_gn = std::atoi(e) != 0;
     u->cfg.freqs = nullptr;
     const int rc = describe(u);
     if (rc != SISIC_OK) { delete u; return rc; }

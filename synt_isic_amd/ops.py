@@ -72,7 +72,10 @@ def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bias=None, x2=None, stride=1,
            upsample=False, gn_scale=None, gn_shift=None, gn_silu=False, chan_bias=None, residual=None,
-           relu=False, tile_cfg=0, w_winograd=None) -> torch.Tensor:
+           relu=False, tile_cfg=0, w_winograd=None, with_stats=False):
+    """sisic_conv2d.  with_stats=True also returns the GroupNorm partials the epilogue wrote, as a
+    [B, Cout, slots, 4] tensor of (count, sum, centred M2, 0), or None when this launch cannot produce them
+    (sisic_conv_stats_slots() == 0)."""
     lib = _lib.load()
     B, c0, H, W = x.shape
     c1 = 0 if x2 is None else x2.shape[1]
@@ -91,8 +94,28 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bi
     a.residual = _ptr(residual, "residual"); a.relu = int(relu)
     a.out = out.data_ptr(); a.tile_cfg = tile_cfg
     a.w_winograd = _ptr(w_winograd, "w_winograd")
+    stats = None
+    if with_stats:
+        slots = lib.sisic_conv_stats_slots(C.byref(a))
+        if slots > 0:
+            stats = torch.empty((B, cout, slots, 4), dtype=torch.float32, device=x.device)
+            a.stats_out = stats.data_ptr()
     check(lib.sisic_conv2d(context(x.device), C.byref(a), _stream(x.device)))
-    return out
+    return (out, stats) if with_stats else out
+
+
+def groupnorm_finalize(stats: torch.Tensor, hw: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                       stats2: Optional[torch.Tensor] = None):
+    """scale/shift of GroupNorm over the (concatenated) producers' outputs from their epilogue partials."""
+    lib = _lib.load()
+    B, c0, slots0, _ = stats.shape
+    c1, slots1 = (0, 0) if stats2 is None else (stats2.shape[1], stats2.shape[2])
+    scale = torch.empty((B, c0 + c1), dtype=torch.float32, device=stats.device)
+    shift = torch.empty_like(scale)
+    check(lib.sisic_groupnorm_finalize(context(stats.device), _ptr(stats, "stats"), c0, slots0, _ptr(stats2, "stats2"),
+                                       c1, slots1, B, hw, groups, float(eps), _ptr(gamma, "gamma"), _ptr(beta, "beta"),
+                                       scale.data_ptr(), shift.data_ptr(), _stream(stats.device)))
+    return scale, shift
 
 
 def groupnorm_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,

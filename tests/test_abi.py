@@ -52,6 +52,6 @@ def test_struct_layout_matches_header():
     from synt_isic_amd import _lib
     P, I, F = ctypes.sizeof(ctypes.c_void_p), ctypes.sizeof(ctypes.c_int), ctypes.sizeof(ctypes.c_float)
     assert P == 8 and I == 4
-    assert ctypes.sizeof(_lib.ConvArgs) == 152
-    assert _lib.ConvArgs.w_packed.offset == 48 and _lib.ConvArgs.out.offset == 128 and _lib.ConvArgs.w_winograd.offset == 144
+    assert ctypes.sizeof(_lib.ConvArgs) == 160
+    assert _lib.ConvArgs.w_packed.offset == 48 and _lib.ConvArgs.out.offset == 128 and _lib.ConvArgs.w_winograd.offset == 144 and _lib.ConvArgs.stats_out.offset == 152
     assert ctypes.sizeof(_lib.UNetConfigC) == 4 * 4 + 3 * 32 + 4 * 4 + 8

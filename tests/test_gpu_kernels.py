@@ -316,6 +316,103 @@ def test_groupnorm_large_mean_is_stable():
     assert (got - ref).abs().max().item() < 5e-3      # fp32 input quantisation at |x|=100 dominates
 
 
+@pytest.mark.parametrize("cfg,B,H,W,ups", [(66, 3, 32, 32, False), (62, 2, 18, 10, False), (60, 2, 9, 23, False),
+                                           (64, 2, 16, 16, True), (61, 5, 8, 8, False), (67, 3, 6, 10, False),
+                                           (0, 2, 64, 64, False)])
+def test_conv_epilogue_groupnorm_partials(cfg, B, H, W, ups):
+    """sisic_conv_args.stats_out: the Winograd output transform leaves (count, sum, centred M2) per image, channel and
+    workgroup tile; sisic_groupnorm_finalize on them == sisic_groupnorm_stats on the stored tensor."""
+    from synt_isic_amd import ops
+    cin, cout, G, eps = 24, 96, 32, 1e-5
+    x = _rand(B, cin, H, W, seed=160)
+    w = _rand(cout, cin, 3, 3, seed=161, scale=0.1)
+    b = 3.0 * _rand(cout, seed=162)
+    res = _rand(B, cout, 2 * H if ups else H, 2 * W if ups else W, seed=163)
+    d = lambda t: t.to(DEV).contiguous()
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 3, bias=d(b), residual=d(res), upsample=ups,
+                       tile_cfg=cfg, w_winograd=ops.pack_winograd_weight(d(w)), with_stats=True)
+    assert st is not None and st.shape[:2] == (B, cout) and st.shape[3] == 4
+    yc, stc = y.cpu().double(), st.cpu().double()
+    n, s1, m2 = stc[..., 0].sum(-1), stc[..., 1].sum(-1), stc[..., 2]
+    assert torch.equal(n, torch.full_like(n, yc.shape[2] * yc.shape[3]))
+    _close(s1.float(), yc.sum((2, 3)), tol=1e-5, what="partial sums")
+    mean_i = stc[..., 1] / stc[..., 0].clamp(min=1)
+    mean = (s1 / n)[..., None]
+    m2_tot = m2.sum(-1) + (stc[..., 0] * (mean_i - mean) ** 2).sum(-1)
+    _close(m2_tot.float(), ((yc - yc.mean((2, 3), keepdim=True)) ** 2).sum((2, 3)), tol=1e-5, what="merged M2")
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=164), 0.1 * _rand(cout, seed=165)
+    sc, sh = ops.groupnorm_finalize(st, yc.shape[2] * yc.shape[3], d(gamma), d(beta), G, eps)
+    sc0, sh0 = ops.groupnorm_stats(y, d(gamma), d(beta), G, eps)
+    _close(sc, sc0.cpu().double(), tol=2e-6, what="finalize scale")
+    _close(sh, sh0.cpu().double(), tol=2e-6, what="finalize shift")
+    ref = F.group_norm(yc, G, gamma.double(), beta.double(), eps)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=2e-5, what="groupnorm from partials")
+    # launches that cannot produce partials say so instead of writing nothing (vector-ALU kernel for Cout <= 4)
+    y2, st2 = ops.conv2d(d(x), ops.pack_conv_weight(d(w[:3].contiguous())), 3, 3, with_stats=True)
+    assert st2 is None
+
+
+@pytest.mark.parametrize("ksize,stride,cfg,B,H,W", [(3, 1, 16, 3, 8, 8), (3, 1, 8, 2, 32, 32), (3, 1, 9, 2, 18, 10), (3, 1, 1, 1, 64, 64),
+                                                    (3, 2, 11, 2, 64, 64), (3, 2, 13, 2, 16, 16), (3, 2, 0, 2, 30, 22),
+                                                    (1, 1, 24, 2, 32, 32), (1, 1, 25, 2, 16, 16), (1, 1, 22, 3, 8, 8), (1, 1, 0, 2, 9, 23)])
+def test_direct_conv_epilogue_groupnorm_partials(ksize, stride, cfg, B, H, W):
+    """the direct MFMA kernel's partials (one slot per pixel tile and pixel-wave) -> same GroupNorm as the pass over
+    the stored tensor; Cout = 70 leaves a partly filled channel tile."""
+    from synt_isic_amd import ops
+    cin, cout, G, eps = 24, 70, 35, 1e-5
+    x = _rand(B, cin, H, W, seed=180)
+    w = _rand(cout, cin, ksize, ksize, seed=181, scale=0.1)
+    b = 2.0 * _rand(cout, seed=182)
+    d = lambda t: t.to(DEV).contiguous()
+    Ho, Wo = (H + 2 * (ksize // 2) - ksize) // stride + 1, (W + 2 * (ksize // 2) - ksize) // stride + 1
+    res = _rand(B, cout, Ho, Wo, seed=183)
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, ksize, bias=d(b), residual=d(res), stride=stride,
+                       tile_cfg=cfg, with_stats=True)
+    assert st is not None and st.shape[:2] == (B, cout)
+    yc, stc = y.cpu().double(), st.cpu().double()
+    assert torch.equal(stc[..., 0].sum(-1), torch.full((B, cout), float(Ho * Wo), dtype=torch.float64))
+    _close(stc[..., 1].sum(-1).float(), yc.sum((2, 3)), tol=1e-5, what="partial sums")
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=184), 0.1 * _rand(cout, seed=185)
+    sc, sh = ops.groupnorm_finalize(st, Ho * Wo, d(gamma), d(beta), G, eps)
+    ref = F.group_norm(yc, G, gamma.double(), beta.double(), eps)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=2e-5, what=f"groupnorm from direct-conv partials k{ksize} s{stride} cfg{cfg}")
+
+
+def test_groupnorm_finalize_concat_and_large_mean():
+    """two producers with different slot counts and a group that straddles the seam (18 + 14 channels in 8 groups of
+    4); and |mean| >> std, where raw second moments would lose the variance."""
+    from synt_isic_amd import ops
+    d = lambda t: t.to(DEV).contiguous()
+    B, G, eps = 2, 8, 1e-5
+    xa = _rand(B, 16, 32, 32, seed=170)
+    xb = _rand(B, 16, 32, 32, seed=171)
+    wa, wb = _rand(18, 16, 3, 3, seed=172, scale=0.1), _rand(14, 16, 3, 3, seed=173, scale=0.1)   # group 4 = channels 16..19 straddles
+    ya, sa = ops.conv2d(d(xa), ops.pack_conv_weight(d(wa)), 18, 3, tile_cfg=66, w_winograd=ops.pack_winograd_weight(d(wa)), with_stats=True)
+    yb, sb = ops.conv2d(d(xb), ops.pack_conv_weight(d(wb)), 14, 3, tile_cfg=67, w_winograd=ops.pack_winograd_weight(d(wb)), with_stats=True)
+    assert sa.shape[2] == 4 and sb.shape[2] == 16
+    gamma, beta = 1.0 + 0.1 * _rand(32, seed=174), 0.1 * _rand(32, seed=175)
+    sc, sh = ops.groupnorm_finalize(sa, 32 * 32, d(gamma), d(beta), G, eps, stats2=sb)
+    full = torch.cat([ya, yb], 1).cpu().double()
+    ref = F.group_norm(full, G, gamma.double(), beta.double(), eps)
+    got = full * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=2e-5, what="concat groupnorm from partials")
+    # identity filter + bias 100: output = 1e-2 * noise + 100
+    C = 32
+    x = _rand(1, C, 16, 16, seed=176) * 1e-2
+    w = torch.zeros(C, C, 3, 3)
+    for c in range(C):
+        w[c, c, 1, 1] = 1.0
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), C, 3, bias=d(torch.full((C,), 100.0)), tile_cfg=66,
+                       w_winograd=ops.pack_winograd_weight(d(w)), with_stats=True)
+    sc, sh = ops.groupnorm_finalize(st, 256, d(torch.ones(C)), d(torch.zeros(C)), 32, eps)
+    yc = y.cpu().double()
+    ref = F.group_norm(yc, 32, eps=eps)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    assert (got - ref).abs().max().item() < 5e-3
+
+
 # ---------------------------------------------------------------------------------- attention
 def _attn_ref(qkv, heads):
     B, C3, N = qkv.shape

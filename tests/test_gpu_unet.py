@@ -125,3 +125,19 @@ def test_reload_weights_and_second_instance(synthetic_sd):
     assert str(cpu.device) == "cpu"
     with pytest.raises(RuntimeError, match="MI355X only"):
         cpu(x, 50)
+
+
+def test_groupnorm_from_conv_epilogues_matches_standalone_pass(model, synthetic_sd, monkeypatch):
+    """the executor takes GroupNorm statistics from the producing convolutions' epilogues where it can
+    (sisic_conv_args.stats_out + sisic_groupnorm_finalize); SISIC_FUSED_GN=0 forces the stand-alone statistics
+    pass everywhere.  Both are the same network to fp32 rounding."""
+    from synt_isic_amd.unet import HipUNet2DModel
+    monkeypatch.setenv("SISIC_FUSED_GN", "0")
+    plain = HipUNet2DModel()
+    plain.load_state_dict(synthetic_sd)
+    plain = plain.to(DEV).eval()
+    monkeypatch.delenv("SISIC_FUSED_GN")
+    for shape, t in (((2, 3, 64, 64), 321), ((1, 3, 40, 24), 7)):
+        x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        a, b = model(x, t).sample, plain(x, t).sample
+        assert (a - b).abs().max().item() <= 2e-5
