@@ -11,15 +11,19 @@
 //     "swapped" so the query sits on the lane and its keys in the 16 accumulator registers:
 //     the softmax row reduction is register-local plus one cross-half shuffle;
 //   * softmax in fp32, online (running max / sum / output) across 32-key tiles and key blocks;
-//   * P.V on the vector ALU: with d=8 the MFMA tile would be 3/4 padding, while the keys a lane
-//     holds in registers 4q..4q+3 are 4 consecutive V columns = one broadcast ds_read_b128.
+//   * P.V on the vector ALU: with d=8 the MFMA tile would be 3/4 padding (and fp32 MFMA is only twice the packed
+//     vector rate).  V sits in LDS as [key][d], so one key's eight values are two broadcast ds_read_b128 whose
+//     register pairs feed v_pk_fma_f32 directly: four packed FMAs per (query, key), no operand shuffling.
 //
 // Algorithmic bytes per launch: 4*B*4*C*N (q,k,v in, o out).  FLOPs: 4*B*C*N*N.
+#include <type_traits>
+
 #include "common.h"
 
 namespace sisic {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int ATT_D = 8;
 constexpr int ATT_KB = 256;       // keys per LDS block
@@ -48,73 +52,95 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
     const float* Kp = Qp + (size_t)C * N;
     const float* Vp = Kp + (size_t)C * N;
 
+    // the softmax scale is folded into q once, so the score tile needs no multiply
     float qreg[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qreg[s] = (q < N) ? Qp[(size_t)(2 * s + half) * N + q] : 0.0f;
+    for (int s = 0; s < 4; ++s) qreg[s] = (q < N) ? Qp[(size_t)(2 * s + half) * N + q] * scale : 0.0f;
 
     float m_run = -INFINITY, l_part = 0.0f;
-    float o[ATT_D];
+    f32x2 o2[ATT_D / 2];
 #pragma unroll
-    for (int d = 0; d < ATT_D; ++d) o[d] = 0.0f;
+    for (int d = 0; d < ATT_D / 2; ++d) o2[d] = f32x2{0.0f, 0.0f};
+
+    // One pass per 32-key tile with an online softmax (running maximum m_run, running sum l_part, running
+    // output o2[]): S^T tile on the MFMA pipe, tile maximum, rescale of the running state when the maximum
+    // grows, p = exp(s - m), row sum and P.V.  (A two-pass form that recomputed S^T spent twice the matrix
+    // work for the same result; on this chip matrix and vector instructions of one SIMD do not overlap.)
+    // MASKED: the tile reaches past the last key (only the final tile of a sequence that is no multiple of 32).
+    auto tile = [&](const int kt, const int nk, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
+            S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (MASKED) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                S[r] = (key < nk) ? S[r] : -INFINITY;
+            }
+            tmax = fmaxf(tmax, S[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);     // first tile: exp(-inf) = 0; unchanged maximum: 1
+        l_part *= alpha;
+#pragma unroll
+        for (int d = 0; d < ATT_D / 2; ++d) o2[d] *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            float pv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pv[i] = __expf(S[4 * rq + i] - m_new);   // masked keys: exp(-inf) = 0
+            l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+            const int koff = kt * 32 + 8 * rq + 4 * half;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 va = *reinterpret_cast<const float4*>(&Vs[(koff + i) * ATT_D]);
+                const float4 vb = *reinterpret_cast<const float4*>(&Vs[(koff + i) * ATT_D + 4]);
+                const f32x2 p2 = f32x2{pv[i], pv[i]};
+                o2[0] += p2 * f32x2{va.x, va.y};
+                o2[1] += p2 * f32x2{va.z, va.w};
+                o2[2] += p2 * f32x2{vb.x, vb.y};
+                o2[3] += p2 * f32x2{vb.z, vb.w};
+            }
+        }
+    };
 
     for (int kb0 = 0; kb0 < N; kb0 += ATT_KB) {
         __syncthreads();
-        for (int idx = tid; idx < ATT_D * ATT_KB; idx += 64 * ATT_WAVES) {
+        for (int idx = tid; idx < ATT_D * ATT_KB; idx += 64 * ATT_WAVES) {     // K: [d][key]
             const int d = idx / ATT_KB, k = idx % ATT_KB;
             const int key = kb0 + k;
-            const bool v = key < N;
-            Ks[idx] = v ? Kp[(size_t)d * N + key] : 0.0f;
-            Vs[idx] = v ? Vp[(size_t)d * N + key] : 0.0f;
+            Ks[idx] = key < N ? Kp[(size_t)d * N + key] : 0.0f;
+        }
+        for (int k = tid; k < ATT_KB; k += 64 * ATT_WAVES) {                   // V: [key][d], one key per thread
+            const int key = kb0 + k;
+            float v[ATT_D];
+#pragma unroll
+            for (int d = 0; d < ATT_D; ++d) v[d] = key < N ? Vp[(size_t)d * N + key] : 0.0f;
+            *reinterpret_cast<float4*>(&Vs[k * ATT_D]) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(&Vs[k * ATT_D + 4]) = make_float4(v[4], v[5], v[6], v[7]);
         }
         __syncthreads();
         if (!wave_active) continue;
         const int nk = min(ATT_KB, N - kb0);
-
-        // One pass per 32-key tile with an online softmax (running maximum m_run, running sum l_part, running
-        // output o[]): S^T tile on the MFMA pipe, tile maximum, rescale of the running state when the maximum
-        // grows, p = exp(s - m), row sum and P.V.  (A two-pass form that recomputed S^T spent twice the matrix
-        // work for the same result; on this chip matrix and vector instructions of one SIMD do not overlap.)
 #pragma unroll 1
-        for (int kt = 0; kt < ATT_KT; ++kt) {
-            if (kt * 32 >= nk) break;
-            f32x16 S;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
-                S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
-            }
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                S[r] = (key < nk) ? S[r] * scale : -INFINITY;
-                tmax = fmaxf(tmax, S[r]);
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __expf(m_run - m_new);     // first tile: exp(-inf) = 0; unchanged maximum: 1
-            l_part *= alpha;
-#pragma unroll
-            for (int d = 0; d < ATT_D; ++d) o[d] *= alpha;
-            m_run = m_new;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                float pv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pv[i] = __expf(S[4 * rq + i] - m_new);   // masked keys: exp(-inf) = 0
-                l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-                const int koff = kt * 32 + 8 * rq + 4 * half;
-#pragma unroll
-                for (int d = 0; d < ATT_D; ++d) {
-                    const float4 v = *reinterpret_cast<const float4*>(&Vs[d * ATT_KB + koff]);
-                    o[d] += (pv[0] * v.x + pv[1] * v.y) + (pv[2] * v.z + pv[3] * v.w);
-                }
-            }
+        for (int kt = 0; kt * 32 < nk; ++kt) {
+            if (kt * 32 + 32 <= nk) tile(kt, nk, std::false_type{});
+            else tile(kt, nk, std::true_type{});
         }
     }
 
+    float o[ATT_D];
+#pragma unroll
+    for (int d = 0; d < ATT_D / 2; ++d) { o[2 * d] = o2[d].x; o[2 * d + 1] = o2[d].y; }
 
     if (wave_active) {
         const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
@@ -126,7 +152,9 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
             float* Op = out + ((size_t)b * C + (size_t)head * ATT_D) * N + q;
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {
-                const float v = half ? res[4 + dd] : res[dd];
+                // bitwise select: a plain ?: on the array makes hipcc index it through scratch memory
+                const int hm = -half;
+                const float v = __int_as_float((__float_as_int(res[dd]) & ~hm) | (__float_as_int(res[4 + dd]) & hm));
                 Op[(size_t)(4 * half + dd) * N] = v;
             }
         }
