@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import ctypes as C
 import hashlib
+import os
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -61,6 +63,87 @@ def draw_noise(seeds: Sequence[int], n_noise_steps: int, chw: Tuple[int, int, in
     return x_T, z
 
 
+class NoiseStream:
+    """The same noise as ``draw_noise``, produced while the GPU samples.
+
+    ``draw_noise`` materialises every z_t first: 786 M normals (3.1 GB) for 64 images at 64x64, T=1000 -- seconds of
+    single-threaded RNG in front of an 8 s sampling run.  Here the per-image generators are advanced on worker
+    threads, one segment of steps at a time, into two pinned buffers that are uploaded on a side stream; the sampler
+    consumes segment k while segment k+1 is drawn.  One big ``randn`` of n*numel values equals n consecutive draws of
+    numel values (numel is a multiple of 16), and each generator is only ever advanced by one task at a time, so the
+    stream is bit-identical to ``draw_noise`` whatever the segment length or worker count.
+    """
+
+    def __init__(self, seeds: Sequence[int], chw: Tuple[int, int, int], device: torch.device, segment_steps: int,
+                 workers: Optional[int] = None):
+        self.chw = tuple(chw)
+        self.B = len(seeds)
+        self.device = device
+        self.seg = max(1, int(segment_steps))
+        if workers is None:
+            try:
+                cpus = len(os.sched_getaffinity(0))
+            except AttributeError:                      # pragma: no cover
+                cpus = os.cpu_count() or 1
+            workers = max(1, min(self.B, cpus, 16))
+        self.pool = ThreadPoolExecutor(max_workers=workers)
+        self.gens = []
+        for sd in seeds:
+            g = torch.Generator(device="cpu")
+            g.manual_seed(int(sd))
+            self.gens.append(g)
+        self.x_T = torch.empty((self.B,) + self.chw, dtype=torch.float32)
+        list(self.pool.map(self._draw_x, range(self.B)))
+        shape = (self.seg, self.B) + self.chw
+        self.host = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.dev = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]      # upload of slot i finished
+        self.uploaded = [False, False]
+        self.consumed = [None, None]                               # event after the sampler's last read of slot i
+        self.pending = [None, None]
+
+    def _draw_x(self, b: int) -> None:
+        self.x_T[b] = torch.randn((1,) + self.chw, generator=self.gens[b])[0]
+
+    def _draw_z(self, slot: int, n: int, b: int) -> None:
+        self.host[slot][:n, b] = torch.randn((n,) + self.chw, generator=self.gens[b])
+
+    def prefetch(self, slot: int, n: int) -> None:
+        """start drawing the next n noise tensors of every image into pinned buffer ``slot``"""
+        if n <= 0:
+            self.pending[slot] = []
+            return
+        if self.uploaded[slot]:
+            self.ready[slot].synchronize()           # the previous upload out of this pinned buffer has completed
+        self.pending[slot] = [self.pool.submit(self._draw_z, slot, n, b) for b in range(self.B)]
+
+    def acquire(self, slot: int, n: int) -> Optional[torch.Tensor]:
+        """wait for the draws of ``slot``, upload them on the side stream and make the current stream wait"""
+        if n <= 0:
+            return None
+        for f in self.pending[slot]:
+            f.result()
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[slot] is not None:
+                self.copy_stream.wait_event(self.consumed[slot])
+            self.dev[slot][:n].copy_(self.host[slot][:n], non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+            self.uploaded[slot] = True
+        cur.wait_event(self.ready[slot])
+        return self.dev[slot][:n]
+
+    def release(self, slot: int) -> None:
+        """the sampler's reads of ``slot`` are enqueued on the current stream"""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.consumed[slot] = ev
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=True)
+
+
 @dataclass
 class SampleResult:
     images: torch.Tensor                       # uint8 [B,H,W,3] on the GPU
@@ -74,9 +157,12 @@ class SampleResult:
 
 @torch.no_grad()
 def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch.Tensor,
-                      noise: Optional[torch.Tensor], *, return_trajectory: bool = False,
+                      noise, *, return_trajectory: bool = False,
                       cancel_flag: Optional[C.c_int] = None) -> SampleResult:
-    """x_T: GPU fp32 [B,C,H,W]; noise: GPU fp32 [n_noise,B,C,H,W] or None (no noise added)."""
+    """x_T: GPU fp32 [B,C,H,W]; noise: GPU fp32 [n_noise,B,C,H,W], None (no noise added), or a ``NoiseStream``
+    (the loop then runs segment by segment while the stream draws and uploads the next segment's noise)."""
+    if isinstance(noise, NoiseStream):
+        return _run_streamed(model, scheduler, x_T, noise, return_trajectory, cancel_flag)
     lib = _lib.load()
     dev = x_T.device
     if dev.type != "cuda":
@@ -107,6 +193,49 @@ def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: t
                         steps_done=done.value)
 
 
+def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch.Tensor, ns: NoiseStream,
+                  return_trajectory: bool, cancel_flag: Optional[C.c_int]) -> SampleResult:
+    lib = _lib.load()
+    dev = x_T.device
+    B, Cc, H, W = x_T.shape
+    ts = scheduler.timesteps.to(torch.int64).contiguous()
+    T = ts.numel()
+    coef = scheduler.coefficient_table().contiguous()
+    needs = (coef[:, 4] != 0).to(torch.int64)                   # 1 where the step adds noise
+    bounds = list(range(0, T, ns.seg)) + [T]
+    counts = [int(needs[a:b].sum()) for a, b in zip(bounds[:-1], bounds[1:])]
+    x = x_T.to(torch.float32).contiguous().clone()
+    traj = torch.empty((T, B, Cc, H, W), dtype=torch.float32, device=dev) if return_trajectory else None
+    out_u8 = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=dev)
+    clip = scheduler.config.clip_sample_range if scheduler.config.clip_sample else 0.0
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    n_elem = B * Cc * H * W
+    done_total, rc = 0, 0
+    ns.prefetch(0, counts[0])
+    for k, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        slot = k & 1
+        z = ns.acquire(slot, counts[k])
+        if k + 1 < len(counts):
+            ns.prefetch(slot ^ 1, counts[k + 1])                # drawn while the GPU runs this segment
+        done = C.c_int(0)
+        last = b == T
+        rc = lib.sisic_sample(model.handle, x.data_ptr(), B, H, W, b - a,
+                              C.cast(ts[a:b].contiguous().data_ptr(), _lib.c_int64_p),
+                              C.cast(coef[a:b].contiguous().data_ptr(), _lib.c_float_p), float(clip),
+                              z.data_ptr() if z is not None else None,
+                              traj.data_ptr() + a * n_elem * 4 if traj is not None else None,
+                              out_u8.data_ptr() if last else None,
+                              C.byref(cancel_flag) if cancel_flag is not None else None, C.byref(done), stream)
+        ns.release(slot)
+        done_total += done.value
+        if rc != 0:
+            break
+    if rc != _lib.SISIC_ECANCEL:
+        check(rc)
+    return SampleResult(images=out_u8, latents=x, trajectory=traj, timesteps=[int(t) for t in ts],
+                        steps_done=done_total)
+
+
 class Sampler:
     """Holds one loaded UNet per class, like ``ModelManager.loaded_models`` (model_manager.py:19-171)."""
 
@@ -115,6 +244,7 @@ class Sampler:
         self.beta_schedule = beta_schedule
         self.models: Dict[str, HipUNet2DModel] = {}
         self.cancel = C.c_int(0)          # cooperative stop flag (image_generator.py:320,396)
+        self.noise_segment_steps = 64     # steps of noise drawn and uploaded per pipeline stage (NoiseStream)
 
     def add_model(self, class_name: str, state_dict: Dict[str, torch.Tensor], **unet_kwargs) -> HipUNet2DModel:
         m = HipUNet2DModel(**unet_kwargs)
@@ -141,10 +271,16 @@ class Sampler:
         sched = self.create_scheduler(T)
         n_noise = sum(1 for t in sched.timesteps if int(t) > 0)
         H, W = size
-        x_T, z = draw_noise(seeds, n_noise, (model.config.in_channels, H, W), pin=True)
-        hashes = [noise_hash(x_T[b:b + 1]) for b in range(len(seeds))]
-        res = run_sampling_loop(model, sched, x_T.to(self.device), z.to(self.device, non_blocking=True),
-                                return_trajectory=return_trajectory, cancel_flag=self.cancel)
+        # noise is drawn segment by segment on worker threads while the GPU samples (NoiseStream); the values are
+        # those of draw_noise(seeds, n_noise, ...)
+        ns = NoiseStream(seeds, (model.config.in_channels, H, W), self.device, self.noise_segment_steps)
+        try:
+            hashes = [noise_hash(ns.x_T[b:b + 1]) for b in range(len(seeds))]
+            res = run_sampling_loop(model, sched, ns.x_T.to(self.device), ns if n_noise else None,
+                                    return_trajectory=return_trajectory, cancel_flag=self.cancel)
+            torch.cuda.current_stream(self.device).synchronize()
+        finally:
+            ns.close()
         res.seeds = [int(s) for s in seeds]
         res.noise_hashes = hashes
         return res

@@ -161,3 +161,36 @@ def test_noise_shape_is_validated(sampler):
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_streamed_noise_equals_materialised_noise(sampler):
+    """generate_seeds draws z on worker threads segment by segment while the GPU samples (NoiseStream); the values and
+    therefore every latent of the trajectory equal the all-up-front path, whatever the segment length."""
+    from synt_isic_amd.sampler import draw_noise, run_sampling_loop
+    seeds, T = [7, 8, 9], 11
+    sched = sampler.create_scheduler(T)
+    x_T, z = draw_noise(seeds, T - 1, (3, 32, 32))
+    ref = run_sampling_loop(sampler.models["NV"], sched, x_T.to(DEV), z.to(DEV), return_trajectory=True)
+    old = sampler.noise_segment_steps
+    try:
+        for seg in (1, 3, 4, 11, 64):
+            sampler.noise_segment_steps = seg
+            res = sampler.generate_seeds("NV", seeds, T, (32, 32), return_trajectory=True)
+            assert res.steps_done == T
+            assert torch.equal(res.trajectory, ref.trajectory), f"segment length {seg}"
+            assert torch.equal(res.images, ref.images)
+    finally:
+        sampler.noise_segment_steps = old
+    # the host-side stream alone: bit-identical to draw_noise (CPU values, before any upload)
+    from synt_isic_amd.sampler import NoiseStream
+    ns = NoiseStream(seeds, (3, 32, 32), torch.device(DEV), segment_steps=4, workers=2)
+    try:
+        assert torch.equal(ns.x_T, x_T)
+        got = []
+        for k, n in enumerate((4, 4, 2)):
+            ns.prefetch(k & 1, n)
+            got.append(ns.acquire(k & 1, n).cpu().clone())
+            ns.release(k & 1)
+        assert torch.equal(torch.cat(got), z)
+    finally:
+        ns.close()
