@@ -96,6 +96,7 @@ int sisic_destroy(sisic_ctx* ctx) {
     if (!ctx) return SISIC_OK;
     (void)profile_collect(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->splitk) (void)hipFree(ctx->splitk);
     delete ctx;
     return SISIC_OK;
 }

@@ -60,6 +60,8 @@ struct sisic_ctx {
     sisic::ProfileSlot prof[sisic::PK_COUNT];
     std::vector<sisic::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
+    float* splitk = nullptr;        // partial outputs of K-split convolutions (conv_winograd.hip), grown on demand
+    size_t splitk_floats = 0;
 };
 
 namespace sisic {

@@ -20,6 +20,8 @@
 //
 // Algorithmic bytes per launch: 4*B*(Cin*Hin*Win + Cout*Hout*Wout)
 //   + 4*(Cin*Cout*k*k + Cout) (+ 4*B*Cout*Hout*Wout when a residual is read).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace sisic {
@@ -428,26 +430,36 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 //   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
 //   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
 //   1x1 s2: 31: 2,1,1,4,TW32  32: 2,1,1,4,TW16  33: 1,1,2,2,TW8      7x7 s2: 41: 2,1,1,4,TW32 (CIC 4)
-// Winograd F(2x2,3x3) is taken for 3x3 stride-1 convolutions with transformed filters at hand: when forced by
-// tile_cfg 60..71, or automatically from 12x12 outputs up (per-thread load offsets there are 32-bit).
-static bool winograd_selected(const sisic_conv_args& a) {
-    if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4)) return false;
-    const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
-    const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
-    return (a.tile_cfg >= 60 && a.tile_cfg <= 71) || (a.tile_cfg == 0 && Hout >= 12 && Wout >= 12 && fits32);
-}
-
 static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s, int* slots_query);
 
+// Winograd F(2x2,3x3) is taken for 3x3 stride-1 convolutions with transformed filters at hand: when forced by
+// tile_cfg 60..71 / 90, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
+// there are 32-bit).  Returns the tile configuration, 0 = not Winograd.
+static int winograd_cfg(const sisic_conv_args& a) {
+    if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4)) return 0;
+    if ((a.tile_cfg >= 60 && a.tile_cfg <= 71) || a.tile_cfg == 90) return a.tile_cfg;
+    if (a.tile_cfg != 0) return 0;
+    const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
+    const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
+    if (!fits32) return 0;
+    if (Hout >= 12 && Wout >= 12) return 66;
+    // the 8x8 level: four images per workgroup and the input channels split four ways keep all CUs busy
+    const int Cin = a.c0 + a.c1;
+    static const bool ksplit_on = [] { const char* e = std::getenv("SISIC_KSPLIT"); return !e || std::atoi(e) != 0; }();
+    if (ksplit_on && Hout == 8 && Wout == 8 && a.B >= 32 && Cin >= 128 && Cin % 32 == 0 && a.Cout >= 128) return 90;
+    return 0;
+}
+static bool winograd_selected(const sisic_conv_args& a) { return winograd_cfg(a) != 0; }
+
 // GroupNorm partials (sisic_conv_args.stats_out): the Winograd kernels' output transform leaves one slot per
-// workgroup tile of an image (16x16 outputs, or 8x8 for the four-image tilings); the direct MFMA kernel one per
-// pixel tile and pixel-wave (the dispatch below is asked which tiling it would launch).  The third Winograd form and
-// the vector-ALU small-Cout kernel do not produce them.
+// workgroup tile of an image (16x16 outputs, or 8x8 for the four-image tilings; the K-split form one per image from
+// its reduction); the direct MFMA kernel one per pixel tile and pixel-wave (the dispatch below is asked which tiling
+// it would launch).  The third Winograd form and the vector-ALU small-Cout kernel do not produce them.
 int conv_stats_slots(const sisic_conv_args& a) {
-    if (winograd_selected(a)) {
-        if (a.tile_cfg == 70 || a.tile_cfg == 71) return 0;
+    if (const int cfg = winograd_cfg(a)) {
+        if (cfg == 70 || cfg == 71) return 0;
+        if (cfg == 90) return 1;
         const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
-        const int cfg = a.tile_cfg == 0 ? 66 : a.tile_cfg;
         const int edge = (cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 8 : 16;
         return ((Hout + edge - 1) / edge) * ((Wout + edge - 1) / edge);
     }
@@ -506,9 +518,9 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     // workgroup); the 8x8 level stays on the direct kernel (too few workgroups of 4 images x 64 channels).
     if (use_wino) {
         SISIC_REQUIRE(!slots_query, "conv2d: internal: slot query on the Winograd path");
-        return launch_conv_winograd(ctx, a, a.w_winograd, cfg == 0 ? 66 : cfg, s);
+        return launch_conv_winograd(ctx, a, a.w_winograd, winograd_cfg(a), s);
     }
-    SISIC_REQUIRE(cfg < 60 || cfg > 71, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
+    SISIC_REQUIRE((cfg < 60 || cfg > 71) && cfg != 90, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 4>(ctx, p, s);

@@ -50,6 +50,8 @@ struct WinoParams {
     int relu;
     float* out;
     float* stats;       // optional [B][Cout][groups_y*groups_x][4]: per-workgroup (count, sum, centred M2, 0) of the stored values
+    float* part;        // K-split: raw partial outputs [ksplit][B][Cout][Hc][Wc], summed by splitk_reduce_kernel
+    int ksplit;         // workgroups per output tile, each covering nchunks/ksplit channel chunks (1 = no split)
     int groups_x, groups_y, groups_b, n_co_tiles, nwg, nchunks;
     int stagger;        // 1: half of the waves run MFMA-first, the other half stage-first (see the channel loop)
 };
@@ -125,12 +127,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     }
     const int co_t = work % p.n_co_tiles;
     int grp = work / p.n_co_tiles;
+    const int ks = grp % p.ksplit;          // which share of the input channels (K-split)
+    grp /= p.ksplit;
     const int gx = grp % p.groups_x;
     grp /= p.groups_x;
     const int gy = grp % p.groups_y;
     const int gb = grp / p.groups_y;
     const int oy0 = gy * 2 * TY, ox0 = gx * 2 * TX, b0 = gb * NIMG;
     const int co0 = co_t * W_CO;
+    const int n = p.nchunks / p.ksplit;     // chunks of this workgroup (the host makes ksplit divide nchunks)
+    const int cbase = ks * n;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -199,7 +205,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 
     // All loads are unconditional at clamped, always-valid addresses and masked afterwards (see conv_mfma.hip).
     auto load_halo = [&](int chunk) {
-        const int c = chunk * W_CIC + sci;                 // scalar
+        const int c = (cbase + chunk) * W_CIC + sci;       // scalar
         cval = c < Cin;
         hcc = min(c, Cin - 1);
         const bool first = hcc < p.c0;
@@ -218,7 +224,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         }
     };
     auto load_u = [&](int chunk) {
-        const char* slab = uniform_ptr(p.u + (size_t)chunk * W_CIC * 16 * p.cout_pad + co0);
+        const char* slab = uniform_ptr(p.u + (size_t)(cbase + chunk) * W_CIC * 16 * p.cout_pad + co0);
 #pragma unroll
         for (int i = 0; i < G::UPT; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(slab + uoff[i]);
@@ -328,7 +334,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 
     // ---- software pipeline over the channel chunks, ONE barrier per chunk.  Entering iteration c:
     //   U/V[c&1] hold chunk c;  H[(c+1)&1] holds the staged halo of chunk c+1;  registers hold halo(c+2) and U(c+1).
-    const int n = p.nchunks;
     load_halo(0);
     load_u(0);
     stage_halo(0);
@@ -407,6 +412,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) eoff[i][j] = min(eoy + i, p.Hc - 1) * p.Wc + min(eox + j, p.Wc - 1);
+    // K-split: every share stores its raw partial sums; bias, residual, ReLU and statistics happen in the reduction
+    float* const edst = p.part ? p.part + (size_t)ks * p.B * p.Cout * HWout : p.out;
     float eadd[4][EK], eres[4][EK][2][2];
 #pragma unroll
     for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
@@ -415,14 +422,15 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             const int co = co0 + (q >> 1) * 32 + 16 * (q & 1) + ((tid + k * G::THREADS) >> 6);
             const int coc = min(co, p.Cout - 1);
             float add = 0.0f;
-            if (p.bias) add += p.bias[coc];
-            if (p.chan_bias) add += p.chan_bias[(size_t)ebc * p.chan_bias_stride + coc];
+            if (p.bias && !p.part) add += p.bias[coc];
+            if (p.chan_bias && !p.part) add += p.chan_bias[(size_t)ebc * p.chan_bias_stride + coc];
             eadd[q][k] = add;
             const size_t plane = ((size_t)ebc * p.Cout + coc) * HWout;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) eres[q][k][i][j] = p.residual ? p.residual[plane + eoff[i][j]] : 0.0f;
+                for (int j = 0; j < 2; ++j)
+                    eres[q][k][i][j] = (p.residual && !p.part) ? p.residual[plane + eoff[i][j]] : 0.0f;
         }
     }
 #pragma unroll
@@ -470,17 +478,17 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float v = y[i][j] + eadd[q][k] + eres[q][k][i][j];
-                    if (p.relu) v = fmaxf(v, 0.0f);
+                    if (p.relu && !p.part) v = fmaxf(v, 0.0f);
                     in[i][j] = ok && eoy + i < p.Hc && eox + j < p.Wc;
                     if (in[i][j]) {
-                        p.out[plane + eoff[i][j]] = v;
+                        edst[plane + eoff[i][j]] = v;
                         s1 += v;
                         cnt += 1.0f;
                     }
                     vv[i][j] = v;
                 }
             }
-            if (p.stats) {
+            if (p.stats && !p.part) {
                 // One output channel per wave here (co16 is wave-uniform); lanes are the 64 tiles: all of one image
                 // (NIMG == 1) or 16 per image (NIMG == 4).  Per image and workgroup: (count, sum, sum of squared
                 // deviations from this tile's own mean) -- centred partials, merged exactly by gn_finalize_kernel.
@@ -556,6 +564,54 @@ int64_t winograd_packed_numel(int Cout, int Cin) { return (int64_t)round_up(Cin,
 
 #include "conv_winograd3.inc"
 
+// K-split reduction: out = sum_k part[k] + bias + per-sample channel bias + residual (+ReLU), and the GroupNorm partials
+// of the result.  One wave per (image, channel) plane of HW <= 256 pixels; the plane is the only statistics slot.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int planes, int HW,
+                                                            int Cout, const float* __restrict__ bias,
+                                                            const float* __restrict__ chan_bias, int chan_bias_stride,
+                                                            const float* __restrict__ residual, int relu,
+                                                            float* __restrict__ out, float* __restrict__ stats) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (plane >= planes) return;
+    const int b = plane / Cout, co = plane % Cout;
+    float add = bias ? bias[co] : 0.0f;
+    if (chan_bias) add += chan_bias[(size_t)b * chan_bias_stride + co];
+    const size_t base = (size_t)plane * HW, kstride = (size_t)planes * HW;
+    float v[4];
+    float s1 = 0.0f, cnt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = lane + 64 * i;
+        const bool in = px < HW;
+        const size_t o = base + min(px, HW - 1);
+        float acc = part[o];
+        for (int k = 1; k < ksplit; ++k) acc += part[o + k * kstride];
+        acc += add;
+        if (residual) acc += residual[o];
+        if (relu) acc = fmaxf(acc, 0.0f);
+        if (in) {
+            out[o] = acc;
+            s1 += acc;
+            cnt += 1.0f;
+        }
+        v[i] = acc;
+    }
+    if (stats) {
+        s1 = wave64_sum(s1);
+        cnt = wave64_sum(cnt);
+        const float mean = s1 / fmaxf(cnt, 1.0f);
+        float m2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = v[i] - mean;
+            if (lane + 64 * i < HW) m2 += d * d;
+        }
+        m2 = wave64_sum(m2);
+        if (lane == 0) reinterpret_cast<float4*>(stats)[plane] = make_float4(cnt, s1, m2, 0.0f);
+    }
+}
+
 template <int NIMG, int TY, int TX, int PRO, int NW>
 static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     using G = WinoGeom<NIMG, TY, TX, NW>;
@@ -564,7 +620,9 @@ static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     p.groups_b = cdiv(p.B, NIMG);
     p.n_co_tiles = p.cout_pad / W_CO;
     p.nchunks = cdiv(p.c0 + p.c1, W_CIC);
-    const int64_t nwg = (int64_t)p.groups_x * p.groups_y * p.groups_b * p.n_co_tiles;
+    if (p.ksplit < 1) p.ksplit = 1;
+    SISIC_REQUIRE(p.nchunks % p.ksplit == 0, "conv2d(winograd): %d channel chunks do not split %d ways", p.nchunks, p.ksplit);
+    const int64_t nwg = (int64_t)p.groups_x * p.groups_y * p.groups_b * p.n_co_tiles * p.ksplit;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d(winograd): grid too large");
     p.nwg = (int)nwg;
     auto kern = conv_winograd_kernel<NIMG, TY, TX, PRO, NW>;
@@ -591,6 +649,8 @@ static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
 //          62 / 63: the same two tilings with 16 waves (one transform position per wave, 4 waves per SIMD)
 //          64..67 = 60..63 with the MFMA-first / stage-first phase stagger between SIMD partner waves
 //          70 / 71: third form (conv_winograd3.inc): per-wave transform position, operands built in registers
+//          90: tiling 67 with the input channels split over four workgroups per tile + splitk_reduce_kernel -- for the
+//              8x8 level, where 64 tiles x 64 channels per workgroup leave 3/4 of the CUs without work
 int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s) {
     WinoParams p{};
     p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1;
@@ -603,9 +663,32 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu;
     p.out = a.out;
     p.stats = a.stats_out;
-    SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67 || cfg == 71) ? 4 : 1) < 4294967296.0,
+    SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67 || cfg == 71 || cfg == 90) ? 4 : 1) < 4294967296.0,
                   "conv2d(winograd): per-thread load offsets are 32-bit; this tensor needs the direct kernel");
-    p.stagger = (cfg >= 64 && cfg <= 67) ? 1 : 0;
+    p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
+    p.ksplit = 1;
+    if (cfg == 90) {
+        const int K = 4;
+        const size_t HW = (size_t)p.Hc * p.Wc, planes = (size_t)a.B * a.Cout;
+        SISIC_REQUIRE(HW <= 256 && (cdiv(a.c0 + a.c1, W_CIC) % K) == 0,
+                      "conv2d(winograd K-split): needs <= 256 output pixels per image and a multiple of %d input channels", K * W_CIC);
+        const size_t need = (size_t)K * planes * HW;
+        if (ctx->splitk_floats < need) {
+            SISIC_HIP(hipStreamSynchronize(s));
+            if (ctx->splitk) SISIC_HIP(hipFree(ctx->splitk));
+            ctx->splitk = nullptr; ctx->splitk_floats = 0;
+            SISIC_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->splitk), need * sizeof(float)));
+            ctx->splitk_floats = need;
+        }
+        p.ksplit = K;
+        p.part = ctx->splitk;
+        SISIC_TRY((launch_wino_pro<4, 4, 4, 16>(ctx, p, s)));
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, ctx->splitk, K,
+                           (int)planes, (int)HW, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu,
+                           a.out, a.stats_out);
+        SISIC_HIP(hipGetLastError());
+        return SISIC_OK;
+    }
     switch (cfg) {
         case 70: return launch_wino3_pro<1, 8, 8>(ctx, p, s);
         case 71: return launch_wino3_pro<4, 4, 4>(ctx, p, s);

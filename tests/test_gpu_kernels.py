@@ -193,6 +193,41 @@ def test_conv3x3_winograd_upsample(cfg, H, W):
     _close(_run_wino(x, w, cfg, bias=b, upsample=True), _conv_ref(x, w, b, upsample=True), what=f"winograd upsample cfg{cfg}")
 
 
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(8, 8, 8, 64, 0, 64), (5, 8, 8, 40, 24, 70), (3, 6, 10, 96, 0, 128),
+                                              (32, 8, 8, 128, 0, 128)])
+def test_conv3x3_winograd_ksplit(B, H, W, c0, c1, cout):
+    """tile_cfg 90: the input channels of a tile split over four workgroups + the reduction kernel (bias, embedding,
+    residual, ReLU and the GroupNorm partials move into the reduction); the last case is taken by the auto dispatch."""
+    from synt_isic_amd import ops
+    x = _rand(B, c0, H, W, seed=190)
+    x2 = _rand(B, c1, H, W, seed=191) if c1 else None
+    w = _rand(cout, c0 + c1, 3, 3, seed=192, scale=0.05)
+    b = _rand(cout, seed=193)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=194), 0.3 * _rand(B, c0 + c1, seed=195))
+    cb = _rand(B, cout, seed=196)
+    res = _rand(B, cout, H, W, seed=197)
+    kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True, chan_bias=cb, residual=res)
+    _close(_run_wino(x, w, 90, **kw), _conv_ref(x, w, **kw), tol=3e-5, what="winograd K-split fused")
+    kw = dict(bias=b, x2=x2, relu=True)
+    _close(_run_wino(x, w, 90, **kw), _conv_ref(x, w, **kw), tol=3e-5, what="winograd K-split relu")
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    cfg = 0 if B >= 32 else 90
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 3, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=cfg,
+                       w_winograd=ops.pack_winograd_weight(d(w)), with_stats=True)
+    _close(y, _conv_ref(x, w, bias=b, x2=x2, residual=res), tol=3e-5, what="winograd K-split + stats")
+    assert st is not None and tuple(st.shape) == (B, cout, 1, 4)
+    G = 2 if cout % 32 else 32
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=198), 0.1 * _rand(cout, seed=199)
+    sc, sh = ops.groupnorm_finalize(st, H * W, d(gamma), d(beta), G, 1e-5)
+    yc = y.cpu().double()
+    ref = F.group_norm(yc, G, gamma.double(), beta.double(), 1e-5)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=2e-5, what="groupnorm from K-split reduction partials")
+    from synt_isic_amd._lib import SisicError
+    with pytest.raises(SisicError, match="split"):
+        _run_wino(x[:, :24].contiguous(), w[:, :24].contiguous(), 90)        # 3 chunks do not split four ways
+
+
 def test_conv3x3_winograd_reference_layers_and_identity():
     # identity filter: the transform pair must reproduce the input up to fp32 rounding of the 1/2, 1/4 weights
     C = 64

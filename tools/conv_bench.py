@@ -46,6 +46,9 @@ LAYERS = [
     ("1x1 sc 256+128->128 @32", 1, 256, 128, 128, 32, 1, 1, 0, 0, 0),
     ("1x1 sc 128+64->64 @64", 1, 128, 64, 64, 64, 1, 1, 0, 0, 0),
     ("1x1 sc 256+256->256 @8", 3, 256, 256, 256, 8, 1, 1, 0, 0, 0),
+    # not layers of the network (count 0): per-workgroup cost of a quarter / an eighth of the 8x8 level's channels
+    ("probe 64->256 @8 gn+res", 0, 64, 0, 256, 8, 3, 1, 0, 1, 1),
+    ("probe 128->256 @8 gn", 0, 128, 0, 256, 8, 3, 1, 0, 1, 0),
 ]
 
 
