@@ -101,8 +101,12 @@ struct WinoGeom {
     static constexpr int HPI = HH * HWD;
     static constexpr int HEL = NIMG * HPI;                    // halo elements per channel
     static constexpr int TPC = THREADS / W_CIC;               // threads staging one channel
-    static constexpr int EPT = (HEL + TPC - 1) / TPC;
-    static constexpr int CHS = EPT * TPC;                     // padded channel stride in LDS
+    // Several images per workgroup: when a channel's staging threads cover one image's halo (HPI <= TPC), element i of
+    // a thread IS image i -- the image index is then a compile-time constant (scalar GroupNorm operands, no per-lane
+    // image bookkeeping).  Otherwise the HEL elements are dealt out flat.
+    static constexpr bool PER_IMAGE = NIMG > 1 && HPI <= TPC;
+    static constexpr int EPT = PER_IMAGE ? NIMG : (HEL + TPC - 1) / TPC;
+    static constexpr int CHS = PER_IMAGE ? ((HEL + 1) / 2) * 2 : EPT * TPC;   // (padded) channel stride in LDS
     static constexpr int HBUF = W_CIC * CHS;
     static constexpr int UPT = (W_SLAB / 4) / THREADS;        // float4 of the U slab per thread
     static constexpr size_t LDS_BYTES = (size_t)(4 * W_SLAB + 2 * HBUF) * sizeof(float);
@@ -154,19 +158,20 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     const int sci = (G::TPC == 64) ? wave_u : (wave_u >> 1);
     const int sl = tid % G::TPC;
     unsigned goff[G::EPT];        // BYTE offset of the element inside its (image, channel) plane
-    int gimg[G::EPT];
+    int gimg[G::EPT];             // image of the element (a constant i under PER_IMAGE)
     unsigned vmask = 0;
 #pragma unroll
     for (int i = 0; i < G::EPT; ++i) {
-        const int e = sl + i * G::TPC;
-        const int img = e / G::HPI, r = e % G::HPI;
+        const int e = G::PER_IMAGE ? i * G::HPI + sl : sl + i * G::TPC;
+        const int img = G::PER_IMAGE ? i : e / G::HPI, r = G::PER_IMAGE ? sl : e % G::HPI;
         const int yy = r / G::HWD, xx = r % G::HWD;
         const int y = oy0 - 1 + yy, x = ox0 - 1 + xx;
-        const bool v = e < G::HEL && (b0 + img) < p.B && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
+        const bool v = (G::PER_IMAGE ? sl < G::HPI : e < G::HEL) && (b0 + img) < p.B && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
         goff[i] = v ? 4u * (unsigned)((y >> p.ups) * p.Win + (x >> p.ups)) : 0u;
-        gimg[i] = v ? img : 0;
+        gimg[i] = G::PER_IMAGE ? i : (v ? img : 0);
         vmask |= (v ? 1u : 0u) << i;
     }
+    const bool stage_lane = !G::PER_IMAGE || sl < G::HPI;      // PER_IMAGE: threads past the halo stage nothing
     unsigned uoff[G::UPT];        // byte offset of this thread's float4 inside a filter slab
 #pragma unroll
     for (int i = 0; i < G::UPT; ++i) {
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     float rin[G::EPT];            // halo elements in flight (global -> registers -> H_lds)
     float rw[G::UPT * 4];         // filter slab in flight
     float gsc = 1.0f, gsh = 0.0f;
+    float gsc_i[G::EPT], gsh_i[G::EPT];      // PER_IMAGE: one GroupNorm pair per image (uniform -> scalar loads)
     bool cval = false;
     int hcc = 0;                  // channel of the halo data held in rin
 
@@ -221,6 +227,14 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         if constexpr (PRO != 0) {
             gsc = p.gn_scale[b0 * Cin + hcc];              // uniform index: scalar loads.  NIMG > 1: see stage_halo
             gsh = p.gn_shift[b0 * Cin + hcc];
+            if constexpr (G::PER_IMAGE) {
+#pragma unroll
+                for (int i = 0; i < G::EPT; ++i) {
+                    const int bi = min(b0 + i, p.B - 1);
+                    gsc_i[i] = p.gn_scale[bi * Cin + hcc];
+                    gsh_i[i] = p.gn_shift[bi * Cin + hcc];
+                }
+            }
         }
     };
     auto load_u = [&](int chunk) {
@@ -239,7 +253,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             float v = rin[i];
             if constexpr (PRO != 0) {
                 float sc = gsc, sh = gsh;
-                if constexpr (NIMG > 1) {
+                if constexpr (G::PER_IMAGE) {
+                    sc = gsc_i[i];
+                    sh = gsh_i[i];
+                } else if constexpr (NIMG > 1) {
                     const int bi = min(b0 + gimg[i], p.B - 1);
                     sc = p.gn_scale[(size_t)bi * Cin + hcc];
                     sh = p.gn_shift[(size_t)bi * Cin + hcc];
@@ -247,7 +264,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
                 v = v * sc + sh;
                 if constexpr (PRO == 2) v = wsilu(v);
             }
-            dst[i * G::TPC] = ((m >> i) & 1u) ? v : 0.0f;
+            if (stage_lane) dst[i * (G::PER_IMAGE ? G::HPI : G::TPC)] = ((m >> i) & 1u) ? v : 0.0f;
         }
     };
     auto stage_u = [&](int buf) {
