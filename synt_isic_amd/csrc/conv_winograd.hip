@@ -583,7 +583,8 @@ int64_t winograd_packed_numel(int Cout, int Cin) { return (int64_t)round_up(Cin,
 
 // K-split reduction: out = sum_k part[k] + bias + per-sample channel bias + residual (+ReLU), and the GroupNorm partials
 // of the result.  One wave per (image, channel) plane of HW <= 256 pixels; the plane is the only statistics slot.
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int ksplit, int planes, int HW,
+template <int KSPLIT>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int planes, int HW,
                                                             int Cout, const float* __restrict__ bias,
                                                             const float* __restrict__ chan_bias, int chan_bias_stride,
                                                             const float* __restrict__ residual, int relu,
@@ -595,17 +596,23 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     float add = bias ? bias[co] : 0.0f;
     if (chan_bias) add += chan_bias[(size_t)b * chan_bias_stride + co];
     const size_t base = (size_t)plane * HW, kstride = (size_t)planes * HW;
-    float v[4];
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float s1 = 0.0f, cnt = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        if (64 * i >= HW) break;               // uniform: planes of 64 pixels take one round
         const int px = lane + 64 * i;
         const bool in = px < HW;
         const size_t o = base + min(px, HW - 1);
-        float acc = part[o];
-        for (int k = 1; k < ksplit; ++k) acc += part[o + k * kstride];
+        float pk[KSPLIT];
+#pragma unroll
+        for (int k = 0; k < KSPLIT; ++k) pk[k] = part[o + k * kstride];      // all in flight together
+        const float r = residual ? residual[o] : 0.0f;
+        float acc = pk[0];
+#pragma unroll
+        for (int k = 1; k < KSPLIT; ++k) acc += pk[k];
         acc += add;
-        if (residual) acc += residual[o];
+        acc += r;
         if (relu) acc = fmaxf(acc, 0.0f);
         if (in) {
             out[o] = acc;
@@ -685,7 +692,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
     if (cfg == 90) {
-        const int K = 4;
+        constexpr int K = 4;
         const size_t HW = (size_t)p.Hc * p.Wc, planes = (size_t)a.B * a.Cout;
         SISIC_REQUIRE(HW <= 256 && (cdiv(a.c0 + a.c1, W_CIC) % K) == 0,
                       "conv2d(winograd K-split): needs <= 256 output pixels per image and a multiple of %d input channels", K * W_CIC);
@@ -700,7 +707,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         p.ksplit = K;
         p.part = ctx->splitk;
         SISIC_TRY((launch_wino_pro<4, 4, 4, 16>(ctx, p, s)));
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, ctx->splitk, K,
+        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, ctx->splitk,
                            (int)planes, (int)HW, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu,
                            a.out, a.stats_out);
         SISIC_HIP(hipGetLastError());

@@ -116,6 +116,34 @@ int launch_gn_stats(sisic_ctx* ctx, const float* in0, int c0, const float* in1, 
     return SISIC_OK;
 }
 
+// Sum of a double over the 64 lanes in a fixed order: DPP butterflies on the two 32-bit halves inside each row of 16
+// lanes (a few cycles each; ds_bpermute shuffles cost an LDS round trip per step), then the four row totals by readlane.
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl_sel) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    switch (ctrl_sel) {
+        case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, true); break;
+        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, true); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xf, 0xf, true); break;
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xf, 0xf, true); break;
+    }
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave64_sum_f64(double v) {
+    v += dpp_f64(v, 0);      // quad_perm [1,0,3,2]
+    v += dpp_f64(v, 1);      // quad_perm [2,3,0,1]
+    v += dpp_f64(v, 2);      // row_half_mirror
+    v += dpp_f64(v, 3);      // row_mirror
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        r[i] = __longlong_as_double(((long long)__builtin_amdgcn_readlane(hi, 16 * i) << 32) |
+                                    (unsigned int)__builtin_amdgcn_readlane(lo, 16 * i));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 // Finalize from per-workgroup partials (count, sum, M2 about the partial's own mean): one wave per (image, group).
 // Lanes stride over the (channel, slot) pairs of the group; the pairwise-merge identity
 //     M2 = sum_i M2_i + sum_i n_i (mean_i - mean)^2
@@ -137,6 +165,8 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restric
     const int len0 = (b0 - a0) * slots0;
     const float4* run1 = st1 ? st1 + ((size_t)b * c1 + a1) * slots1 : nullptr;
     const int len1 = st1 ? (b1 - a1) * slots1 : 0;
+    // this lane's output channel (gs <= 64 in every network here; the tail loop below covers larger groups)
+    const float my_gamma = lane < gs ? gamma[ca + lane] : 0.0f, my_beta = lane < gs ? beta[ca + lane] : 0.0f;
     constexpr int KEEP = 4;                                        // partials per lane and producer held in registers
     float4 k0[KEEP], k1[KEEP];
     double n = 0.0, s1 = 0.0, m2 = 0.0;
@@ -154,30 +184,33 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restric
     }
     for (int i = lane + 64 * KEEP; i < len0; i += 64) { const float4 v = run0[i]; n += v.x; s1 += v.y; m2 += v.z; }
     for (int i = lane + 64 * KEEP; i < len1; i += 64) { const float4 v = run1[i]; n += v.x; s1 += v.y; m2 += v.z; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n += __shfl_xor(n, off);
-        s1 += __shfl_xor(s1, off);
-        m2 += __shfl_xor(m2, off);
-    }
+    n = wave64_sum_f64(n);
+    s1 = wave64_sum_f64(s1);
+    m2 = wave64_sum_f64(m2);
     const double mean = s1 / n;
     double between = 0.0;
+    // n_i (mean_i - mean)^2 = (s1_i - n_i mean)^2 / n_i; n_i is a small integer, so its fp32 reciprocal (1 ulp) only
+    // perturbs this term by 1e-7 relative -- no float64 division per partial
     auto dev = [&](const float4 v) {
         if (v.x > 0.0f) {
-            const double d = (double)v.y / (double)v.x - mean;
-            between += (double)v.x * d * d;
+            const double d = (double)v.y - (double)v.x * mean;
+            between += d * d * (double)(1.0f / v.x);
         }
     };
 #pragma unroll
     for (int j = 0; j < KEEP; ++j) { dev(k0[j]); dev(k1[j]); }
     for (int i = lane + 64 * KEEP; i < len0; i += 64) dev(run0[i]);
     for (int i = lane + 64 * KEEP; i < len1; i += 64) dev(run1[i]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) between += __shfl_xor(between, off);
+    between = wave64_sum_f64(between);
     const double var = fmax((m2 + between) / n, 0.0);
     const float rstd = 1.0f / sqrtf((float)var + eps);
     const float meanf = (float)mean;
-    for (int cc = lane; cc < gs; cc += 64) {
+    if (lane < gs) {
+        const float sc = my_gamma * rstd;
+        scale[(size_t)b * C + ca + lane] = sc;
+        shift[(size_t)b * C + ca + lane] = my_beta - meanf * sc;
+    }
+    for (int cc = lane + 64; cc < gs; cc += 64) {
         const int c = ca + cc;
         const float sc = gamma[c] * rstd;
         scale[(size_t)b * C + c] = sc;
