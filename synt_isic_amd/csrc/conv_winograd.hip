@@ -18,6 +18,8 @@
 //
 // Numerics: fp32 throughout; filter transform in float64 rounded once.  Max error vs a float64 conv is a
 // small multiple of the direct kernel's (tests: same 2e-5 * max(1,|ref|) bound).
+#include <type_traits>
+
 #include "common.h"
 
 // Timing-only ablation builds for tools/conv_bench.py (results are wrong): bit 0 skips the MFMAs, bit 1 the
@@ -114,9 +116,18 @@ struct WinoGeom {
     static_assert(CHS % 2 == 0 && HPI % 2 == 0, "float2 transform reads need even strides");
 };
 
-template <int NIMG, int TY, int TX, int PRO, int NW>   // PRO: 0 = no prologue, 1 = GroupNorm apply, 2 = + SiLU
+// UPS (nearest-2x upsampled input, 16 waves): every 4x4 input patch of an even-aligned tile has rows (a, b, b, c) and
+// columns likewise, so B^T d B vanishes on transform row 2 and column 2 -- 7 of the 16 positions are identically zero.
+// Only the other nine are multiplied: eight waves own one position each, four waves share the ninth (one 32x32 tile
+// each), four waves only stage; with waves dealt round-robin to the SIMDs every SIMD carries 9 of the 36 tile products
+// per k-step instead of 16.  Zero positions are neither loaded (filters), written (V) nor read back (output transform).
+constexpr unsigned WINO_UPS_ZERO = 0x4F44u;        // bit xi set: position xi = 4*row + col has row == 2 or col == 2
+constexpr unsigned WINO_UPS_XI = 0xDC754310u;      // nibble w: position of full wave w (0,1,3,4,5,7,12,13); 15 is shared
+
+template <int NIMG, int TY, int TX, int PRO, int NW, bool UPS = false>   // PRO: 0 = no prologue, 1 = GroupNorm apply, 2 = + SiLU
 __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const WinoParams p) {
     using G = WinoGeom<NIMG, TY, TX, NW>;
+    static_assert(!UPS || (NW == 16 && NIMG == 1), "the upsample form is built for one position per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const U_lds = smem;                   // [2][W_SLAB]   ([ci][xi][co])
     float* const V_lds = smem + 2 * W_SLAB;      // [2][W_SLAB]   ([ci][xi][tile])
@@ -190,7 +201,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     }
 
     // ---- MFMA operand bases: wave w owns xi = w*XPW .. w*XPW + XPW-1
-    const int ab_base = half * 16 * 64 + (wave * G::XPW) * 64 + l31;
+    // UPS roles (wave-uniform): 0 = owns position xi_w, 1 = one 32x32 tile (qm, qn) of position 15, 2 = staging only
+    const int role = !UPS ? 0 : (wave_u < 8 ? 0 : (wave_u < 12 ? 1 : 2));
+    const int xi_w = !UPS ? wave * G::XPW : (wave_u < 8 ? (int)((WINO_UPS_XI >> (4 * wave_u)) & 15u) : 15);
+    const int qm = (wave_u >> 1) & 1, qn = wave_u & 1;
+    const int ab_base = half * 16 * 64 + xi_w * 64 + l31;
 
     f32x16 acc[G::XPW][2][2];     // [xi][co tile][tile tile]
 #pragma unroll
@@ -237,7 +252,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             }
         }
     };
+    // a thread's float4 of the filter slab always belongs to position (tid >> 4) & 15
+    const bool u_active = !UPS || !((WINO_UPS_ZERO >> ((tid >> 4) & 15)) & 1u);
     auto load_u = [&](int chunk) {
+        if (!u_active) return;
         const char* slab = uniform_ptr(p.u + (size_t)(cbase + chunk) * W_CIC * 16 * p.cout_pad + co0);
 #pragma unroll
         for (int i = 0; i < G::UPT; ++i) {
@@ -268,6 +286,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         }
     };
     auto stage_u = [&](int buf) {
+        if (!u_active) return;
         float* udst = U_lds + buf * W_SLAB + tid * 4;
 #pragma unroll
         for (int i = 0; i < G::UPT; ++i)
@@ -321,16 +340,26 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 2 * xrh + i;
+                if (UPS && row == 2) continue;                 // identically zero (wave-uniform test)
                 vp[(4 * row + 0) * 64] = t[i][0] - t[i][2];
                 vp[(4 * row + 1) * 64] = t[i][1] + t[i][2];
-                vp[(4 * row + 2) * 64] = t[i][2] - t[i][1];
+                if (!UPS) vp[(4 * row + 2) * 64] = t[i][2] - t[i][1];
                 vp[(4 * row + 3) * 64] = t[i][1] - t[i][3];
             }
         }
     };
-    auto mfma_chunk = [&](int buf) {
+    auto mfma_chunk = [&](int buf, auto role_tag) {
+        constexpr int ROLE = decltype(role_tag)::value;
         const float* A = U_lds + buf * W_SLAB + ab_base;
         const float* Bm = V_lds + buf * W_SLAB + ab_base;
+        if constexpr (ROLE == 2) return;
+        if constexpr (ROLE == 1) {                             // one tile of the shared position, kept in acc[0][0][0]
+#pragma unroll
+            for (int cp = 0; cp < W_CIC / 2; ++cp)
+                acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(2 * cp) * 16 * 64 + qm * 32],
+                                                                    Bm[(2 * cp) * 16 * 64 + qn * 32], acc[0][0][0], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int cp = 0; cp < W_CIC / 2; ++cp) {
 #pragma unroll
@@ -373,46 +402,57 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     // always has a wave feeding it while the partner wave does the vector/LDS work.  Everything inside one
     // barrier interval touches disjoint buffers, so the order within the interval is free.
     const bool mfma_first = p.stagger && (((wave >> 2) & 1) == 0);
-    int c = 0;
-    for (; c + 3 < n; ++c) {                 // steady state, branch-free per role: one basic block per chunk
-        if (mfma_first) {
+    // The loop is instantiated per wave role so that each instance stays one basic block per chunk (a role test
+    // around the MFMAs inside the loop makes hipcc spill the accumulators).  Every instance executes the same barriers.
+    auto channel_loop = [&](auto role_tag) {
+        int c = 0;
+        for (; c + 3 < n; ++c) {                 // steady state, branch-free per role: one basic block per chunk
+            if (mfma_first) {
 #if !(WINO_ABLATE & 1)
-            mfma_chunk(c & 1);
+                mfma_chunk(c & 1, role_tag);
 #endif
-            transform((c + 1) & 1, (c + 1) & 1);
-            stage_u((c + 1) & 1);
-            stage_halo(c & 1);
-            load_halo(c + 3);
-            load_u(c + 2);
-        } else {
+                transform((c + 1) & 1, (c + 1) & 1);
+                stage_u((c + 1) & 1);
+                stage_halo(c & 1);
+                load_halo(c + 3);
+                load_u(c + 2);
+            } else {
 #if !(WINO_ABLATE & 4)
-            transform((c + 1) & 1, (c + 1) & 1);
+                transform((c + 1) & 1, (c + 1) & 1);
 #endif
-            stage_u((c + 1) & 1);
+                stage_u((c + 1) & 1);
 #if !(WINO_ABLATE & 4)
-            stage_halo(c & 1);               // halo(c+2) -> H[c&1] (its previous content, halo(c), was consumed last iteration)
+                stage_halo(c & 1);               // halo(c+2) -> H[c&1] (its previous content, halo(c), was consumed last iteration)
 #endif
-            load_halo(c + 3);
-            load_u(c + 2);
+                load_halo(c + 3);
+                load_u(c + 2);
 #if !(WINO_ABLATE & 1)
-            mfma_chunk(c & 1);
+                mfma_chunk(c & 1, role_tag);
 #endif
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    for (; c < n; ++c) {                     // last (up to) three chunks: same order, guarded
-        if (c + 1 < n) {
-            transform((c + 1) & 1, (c + 1) & 1);
-            stage_u((c + 1) & 1);
-        }
-        if (c + 2 < n) {
-            stage_halo(c & 1);
-            load_u(c + 2);
-        }
+        for (; c < n; ++c) {                     // last (up to) three chunks: same order, guarded
+            if (c + 1 < n) {
+                transform((c + 1) & 1, (c + 1) & 1);
+                stage_u((c + 1) & 1);
+            }
+            if (c + 2 < n) {
+                stage_halo(c & 1);
+                load_u(c + 2);
+            }
 #if !(WINO_ABLATE & 1)
-        mfma_chunk(c & 1);
+            mfma_chunk(c & 1, role_tag);
 #endif
-        __syncthreads();
+            __syncthreads();
+        }
+    };
+    if constexpr (UPS) {
+        if (role == 0) channel_loop(std::integral_constant<int, 0>{});
+        else if (role == 1) channel_loop(std::integral_constant<int, 1>{});
+        else channel_loop(std::integral_constant<int, 2>{});
+    } else {
+        channel_loop(std::integral_constant<int, 0>{});
     }
 
     // ---- output transform: four rounds of 16 output channels through LDS.  Bias, time-embedding and
@@ -453,16 +493,25 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 #pragma unroll
     for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
         const int mt = q >> 1, rbase = 8 * (q & 1);
+        if (role == 0) {
 #pragma unroll
-        for (int x = 0; x < G::XPW; ++x) {
+            for (int x = 0; x < G::XPW; ++x) {
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn) {
+                for (int nn = 0; nn < 2; ++nn) {
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = rbase + rr;
-                    const int row16 = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;     // row within the 16-channel block
-                    M_lds[((wave * G::XPW + x) * 16 + row16) * 64 + nn * 32 + l31] = acc[x][mt][nn][r];
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = rbase + rr;
+                        const int row16 = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;     // row within the 16-channel block
+                        M_lds[((xi_w + x) * 16 + row16) * 64 + nn * 32 + l31] = acc[x][mt][nn][r];
+                    }
                 }
+            }
+        } else if (UPS && role == 1 && mt == qm) {             // this wave's tile of the shared position
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = rbase + rr;
+                const int row16 = (r & 3) + 8 * ((r >> 2) & 1) + 4 * half;
+                M_lds[(15 * 16 + row16) * 64 + qn * 32 + l31] = acc[0][0][0][r];
             }
         }
         __syncthreads();
@@ -471,7 +520,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             const int co16 = (tid + k * G::THREADS) >> 6;       // 1024 (channel, tile) pairs per round
             float m[4][4];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) m[xi >> 2][xi & 3] = M_lds[(xi * 16 + co16) * 64 + et];
+            for (int xi = 0; xi < 16; ++xi)
+                m[xi >> 2][xi & 3] = (UPS && ((WINO_UPS_ZERO >> xi) & 1u)) ? 0.0f : M_lds[(xi * 16 + co16) * 64 + et];
             float s[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -636,7 +686,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int NIMG, int TY, int TX, int PRO, int NW>
+template <int NIMG, int TY, int TX, int PRO, int NW, bool UPS = false>
 static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     using G = WinoGeom<NIMG, TY, TX, NW>;
     p.groups_x = cdiv(p.Wc, 2 * TX);
@@ -649,7 +699,7 @@ static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     const int64_t nwg = (int64_t)p.groups_x * p.groups_y * p.groups_b * p.n_co_tiles * p.ksplit;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d(winograd): grid too large");
     p.nwg = (int)nwg;
-    auto kern = conv_winograd_kernel<NIMG, TY, TX, PRO, NW>;
+    auto kern = conv_winograd_kernel<NIMG, TY, TX, PRO, NW, UPS>;
     static bool attr_set = false;
     if (!attr_set) {
         SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -664,6 +714,10 @@ static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
 template <int NIMG, int TY, int TX, int NW>
 static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     const int pro = (p.gn_scale == nullptr) ? 0 : (p.gn_silu ? 2 : 1);
+    if constexpr (NIMG == 1 && NW == 16) {
+        // nearest-2x input: the nine-position form (cfg 62 keeps the generic kernel for comparison)
+        if (p.ups && p.stagger && pro == 0) return launch_wino<NIMG, TY, TX, 0, NW, true>(ctx, p, s);
+    }
     if (pro == 2) return launch_wino<NIMG, TY, TX, 2, NW>(ctx, p, s);
     if (pro == 1) return launch_wino<NIMG, TY, TX, 1, NW>(ctx, p, s);
     return launch_wino<NIMG, TY, TX, 0, NW>(ctx, p, s);

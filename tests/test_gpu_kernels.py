@@ -185,12 +185,19 @@ def test_conv3x3_winograd(cfg, B, H, W):
 
 
 @pytest.mark.parametrize("cfg,H,W", [(60, 16, 16), (60, 8, 8), (60, 10, 14), (61, 4, 4), (62, 16, 16), (62, 10, 14),
-                                     (63, 4, 4), (70, 16, 16), (70, 10, 14), (71, 4, 4)])
+                                     (63, 4, 4), (70, 16, 16), (70, 10, 14), (71, 4, 4),
+                                     # 66 / auto: the nine-position form for nearest-2x inputs
+                                     (66, 16, 16), (66, 8, 8), (66, 10, 14), (66, 5, 9), (66, 32, 32), (0, 8, 8), (0, 20, 12)])
 def test_conv3x3_winograd_upsample(cfg, H, W):
     x = _rand(2, 24, H, W, seed=120)
     w = _rand(64, 24, 3, 3, seed=121, scale=0.1)
     b = _rand(64, seed=122)
     _close(_run_wino(x, w, cfg, bias=b, upsample=True), _conv_ref(x, w, b, upsample=True), what=f"winograd upsample cfg{cfg}")
+    # Cout not a multiple of 64, residual on the upsampled grid, ReLU
+    w2, b2 = _rand(70, 24, 3, 3, seed=124, scale=0.1), _rand(70, seed=125)
+    res = _rand(2, 70, 2 * H, 2 * W, seed=126)
+    _close(_run_wino(x, w2, cfg, bias=b2, upsample=True, residual=res, relu=True),
+           _conv_ref(x, w2, b2, upsample=True, residual=res, relu=True), what=f"winograd upsample+res cfg{cfg}")
 
 
 @pytest.mark.parametrize("B,H,W,c0,c1,cout", [(8, 8, 8, 64, 0, 64), (5, 8, 8, 40, 24, 70), (3, 6, 10, 96, 0, 128),
