@@ -93,13 +93,14 @@ __device__ __forceinline__ float wave64_sum(float v) {
 
 // NW = waves per workgroup: 8 (two transform positions xi per wave, 128 accumulator registers, 2 waves/SIMD)
 //                       or 16 (one xi per wave, 64 accumulator registers, 4 waves/SIMD).
-template <int NIMG, int TY, int TX, int NW>
+template <int NIMG, int TY, int TX, int NW, bool UPS = false>
 struct WinoGeom {
     static_assert(NIMG * TY * TX == W_TILES, "64 tiles per workgroup");
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     static constexpr int THREADS = 64 * NW;
     static constexpr int XPW = 16 / NW;                       // transform positions per wave
-    static constexpr int HH = 2 * TY + 2, HWD = 2 * TX + 2;   // halo extent per image
+    // halo extent per image; the upsample form stages the LOW-resolution halo (each 4x4 patch is a 3x3 patch there)
+    static constexpr int HH = UPS ? TY + 2 : 2 * TY + 2, HWD = UPS ? TX + 2 : 2 * TX + 2;
     static constexpr int HPI = HH * HWD;
     static constexpr int HEL = NIMG * HPI;                    // halo elements per channel
     static constexpr int TPC = THREADS / W_CIC;               // threads staging one channel
@@ -114,6 +115,7 @@ struct WinoGeom {
     static constexpr size_t LDS_BYTES = (size_t)(4 * W_SLAB + 2 * HBUF) * sizeof(float);
     static_assert(EPT <= 32, "valid mask is 32 bits");
     static_assert(CHS % 2 == 0 && HPI % 2 == 0, "float2 transform reads need even strides");
+    static_assert(!UPS || NIMG == 1, "upsample form: one image per workgroup");
 };
 
 // UPS (nearest-2x upsampled input, 16 waves): every 4x4 input patch of an even-aligned tile has rows (a, b, b, c) and
@@ -126,7 +128,7 @@ constexpr unsigned WINO_UPS_XI = 0xDC754310u;      // nibble w: position of full
 
 template <int NIMG, int TY, int TX, int PRO, int NW, bool UPS = false>   // PRO: 0 = no prologue, 1 = GroupNorm apply, 2 = + SiLU
 __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const WinoParams p) {
-    using G = WinoGeom<NIMG, TY, TX, NW>;
+    using G = WinoGeom<NIMG, TY, TX, NW, UPS>;
     static_assert(!UPS || (NW == 16 && NIMG == 1), "the upsample form is built for one position per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const U_lds = smem;                   // [2][W_SLAB]   ([ci][xi][co])
@@ -176,9 +178,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         const int e = G::PER_IMAGE ? i * G::HPI + sl : sl + i * G::TPC;
         const int img = G::PER_IMAGE ? i : e / G::HPI, r = G::PER_IMAGE ? sl : e % G::HPI;
         const int yy = r / G::HWD, xx = r % G::HWD;
-        const int y = oy0 - 1 + yy, x = ox0 - 1 + xx;
-        const bool v = (G::PER_IMAGE ? sl < G::HPI : e < G::HEL) && (b0 + img) < p.B && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
-        goff[i] = v ? 4u * (unsigned)((y >> p.ups) * p.Win + (x >> p.ups)) : 0u;
+        bool v = (G::PER_IMAGE ? sl < G::HPI : e < G::HEL) && (b0 + img) < p.B;
+        if constexpr (UPS) {      // low-resolution coordinates; hi-res padding rows -1 / Hc are low-res rows -1 / Hin
+            const int y = (oy0 >> 1) - 1 + yy, x = (ox0 >> 1) - 1 + xx;
+            v = v && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+            goff[i] = v ? 4u * (unsigned)(y * p.Win + x) : 0u;
+        } else {
+            const int y = oy0 - 1 + yy, x = ox0 - 1 + xx;
+            v = v && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
+            goff[i] = v ? 4u * (unsigned)((y >> p.ups) * p.Win + (x >> p.ups)) : 0u;
+        }
         gimg[i] = G::PER_IMAGE ? i : (v ? img : 0);
         vmask |= (v ? 1u : 0u) << i;
     }
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     {
         const int t = lane;
         const int img = t / (TY * TX), ty = (t / TX) % TY, tx = t % TX;
-        xf_base = xci * G::CHS + img * G::HPI + (2 * ty) * G::HWD + 2 * tx;
+        xf_base = UPS ? xci * G::CHS + ty * G::HWD + tx : xci * G::CHS + img * G::HPI + (2 * ty) * G::HWD + 2 * tx;
     }
 
     // ---- MFMA operand bases: wave w owns xi = w*XPW .. w*XPW + XPW-1
@@ -296,7 +305,28 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     auto transform = [&](int hbuf, int vbuf) {   // H_lds[hbuf] -> V_lds[vbuf]:  V = B^T d B
         const float* hp = H_lds + hbuf * G::HBUF + xf_base;
         float* vp = V_lds + vbuf * W_SLAB + xci * 16 * 64 + lane;
-        if constexpr (NW == 8) {
+        if constexpr (UPS) {
+            // 3x3 low-resolution patch L; the 4x4 hi-res patch has rows (L0, L1, L1, L2) and columns likewise, so
+            // B^T d B reduces to  rows: L0-L1, 2 L1, (0), L1-L2  and the same three combinations along the columns.
+            // This wave: transform rows 0 and 1 (xrh = 0, from L0, L1) or row 3 (xrh = 1, from L1, L2).
+            float l[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) l[i][j] = hp[(i + xrh) * G::HWD + j];
+            float d[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) d[j] = l[0][j] - l[1][j];              // rows 0 (xrh = 0) / 3 (xrh = 1)
+            const int r0 = xrh ? 3 : 0;
+            vp[(4 * r0 + 0) * 64] = d[0] - d[1];
+            vp[(4 * r0 + 1) * 64] = 2.0f * d[1];
+            vp[(4 * r0 + 3) * 64] = d[1] - d[2];
+            if (!xrh) {                                                        // row 1 = 2 L1
+                vp[(4 * 1 + 0) * 64] = 2.0f * (l[1][0] - l[1][1]);
+                vp[(4 * 1 + 1) * 64] = 4.0f * l[1][1];
+                vp[(4 * 1 + 3) * 64] = 2.0f * (l[1][1] - l[1][2]);
+            }
+        } else if constexpr (NW == 8) {
             float d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -688,7 +718,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 
 template <int NIMG, int TY, int TX, int PRO, int NW, bool UPS = false>
 static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
-    using G = WinoGeom<NIMG, TY, TX, NW>;
+    using G = WinoGeom<NIMG, TY, TX, NW, UPS>;
     p.groups_x = cdiv(p.Wc, 2 * TX);
     p.groups_y = cdiv(p.Hc, 2 * TY);
     p.groups_b = cdiv(p.B, NIMG);
