@@ -201,7 +201,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 
     // ---- transform plan: lane = tile; NW=8: wave = channel (whole 4x4 patch); NW=16: wave = (channel, row half)
     const int xci = (NW == 8) ? wave : (wave >> 1);
-    const int xrh = (NW == 8) ? 0 : (wave & 1);
     int xf_base;
     {
         const int t = lane;
@@ -302,7 +301,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             *reinterpret_cast<float4*>(udst + i * G::THREADS * 4) =
                 make_float4(rw[4 * i + 0], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]);
     };
-    auto transform = [&](int hbuf, int vbuf) {   // H_lds[hbuf] -> V_lds[vbuf]:  V = B^T d B
+    auto transform = [&](int hbuf, int vbuf, auto xrh_tag) {   // H_lds[hbuf] -> V_lds[vbuf]:  V = B^T d B
+        constexpr int xrh = decltype(xrh_tag)::value;      // row half of this wave (NW = 16), fixed per loop instance
         const float* hp = H_lds + hbuf * G::HBUF + xf_base;
         float* vp = V_lds + vbuf * W_SLAB + xci * 16 * 64 + lane;
         if constexpr (UPS) {
@@ -416,7 +416,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     stage_u(0);
     if (n > 1) load_halo(1);
     __syncthreads();
-    transform(0, 0);
+    if (NW == 16 && (wave & 1)) transform(0, 0, std::integral_constant<int, 1>{});
+    else transform(0, 0, std::integral_constant<int, 0>{});
     if (n > 1) {
         stage_halo(1);
         load_u(1);
@@ -432,23 +433,26 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     // always has a wave feeding it while the partner wave does the vector/LDS work.  Everything inside one
     // barrier interval touches disjoint buffers, so the order within the interval is free.
     const bool mfma_first = p.stagger && (((wave >> 2) & 1) == 0);
-    // The loop is instantiated per wave role so that each instance stays one basic block per chunk (a role test
-    // around the MFMAs inside the loop makes hipcc spill the accumulators).  Every instance executes the same barriers.
-    auto channel_loop = [&](auto role_tag) {
+    // The loop is instantiated per wave role (matrix-first or staging-first order, transform row half, upsample role)
+    // and the role is tested ONCE, outside: a role test inside the loop costs exec-mask bookkeeping and ~20 register
+    // moves per chunk (or, with scalar conditions, makes hipcc unswitch the loop and spill the accumulators).
+    // Every instance executes the same barriers.
+    auto channel_loop = [&](auto role_tag, auto first_tag, auto xrh_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         int c = 0;
-        for (; c + 3 < n; ++c) {                 // steady state, branch-free per role: one basic block per chunk
-            if (mfma_first) {
+        for (; c + 3 < n; ++c) {                 // steady state: one basic block per chunk
+            if constexpr (FIRST) {
 #if !(WINO_ABLATE & 1)
                 mfma_chunk(c & 1, role_tag);
 #endif
-                transform((c + 1) & 1, (c + 1) & 1);
+                transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
                 stage_u((c + 1) & 1);
                 stage_halo(c & 1);
                 load_halo(c + 3);
                 load_u(c + 2);
             } else {
 #if !(WINO_ABLATE & 4)
-                transform((c + 1) & 1, (c + 1) & 1);
+                transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
 #endif
                 stage_u((c + 1) & 1);
 #if !(WINO_ABLATE & 4)
@@ -464,7 +468,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         }
         for (; c < n; ++c) {                     // last (up to) three chunks: same order, guarded
             if (c + 1 < n) {
-                transform((c + 1) & 1, (c + 1) & 1);
+                transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
                 stage_u((c + 1) & 1);
             }
             if (c + 2 < n) {
@@ -477,12 +481,24 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             __syncthreads();
         }
     };
+    auto by_order = [&](auto role_tag, auto xrh_tag) {
+        if (mfma_first) channel_loop(role_tag, std::true_type{}, xrh_tag);
+        else channel_loop(role_tag, std::false_type{}, xrh_tag);
+    };
+    auto by_half = [&](auto role_tag) {
+        if constexpr (NW == 8) {
+            by_order(role_tag, std::integral_constant<int, 0>{});
+        } else {
+            if (wave & 1) by_order(role_tag, std::integral_constant<int, 1>{});
+            else by_order(role_tag, std::integral_constant<int, 0>{});
+        }
+    };
     if constexpr (UPS) {
-        if (role == 0) channel_loop(std::integral_constant<int, 0>{});
-        else if (role == 1) channel_loop(std::integral_constant<int, 1>{});
-        else channel_loop(std::integral_constant<int, 2>{});
+        if (role == 0) by_half(std::integral_constant<int, 0>{});
+        else if (role == 1) by_half(std::integral_constant<int, 1>{});
+        else by_half(std::integral_constant<int, 2>{});
     } else {
-        channel_loop(std::integral_constant<int, 0>{});
+        by_half(std::integral_constant<int, 0>{});
     }
 
     // ---- output transform: four rounds of 16 output channels through LDS.  Bias, time-embedding and
