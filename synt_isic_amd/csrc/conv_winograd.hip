@@ -517,25 +517,40 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         for (int j = 0; j < 2; ++j) eoff[i][j] = min(eoy + i, p.Hc - 1) * p.Wc + min(eox + j, p.Wc - 1);
     // K-split: every share stores its raw partial sums; bias, residual, ReLU and statistics happen in the reduction
     float* const edst = p.part ? p.part + (size_t)ks * p.B * p.Cout * HWout : p.out;
+    // One image per workgroup: the output channel of a thread is wave-uniform in every round, so plane base pointers,
+    // bias and embedding are scalar and the per-lane part of every address is the same four 32-bit pixel offsets.
+    // (Several images per workgroup: the image, and with it the plane, varies along the lanes.)
+    constexpr bool SCALAR_PLANE = NIMG == 1;
+    auto round_co = [&](int q, int k) {       // output channel handled in round q, sub-round k (scalar if SCALAR_PLANE)
+        const int w16 = SCALAR_PLANE ? wave_u + k * NW : ((tid + k * G::THREADS) >> 6);
+        return co0 + (q >> 1) * 32 + 16 * (q & 1) + w16;
+    };
     float eadd[4][EK], eres[4][EK][2][2];
 #pragma unroll
     for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
-            const int co = co0 + (q >> 1) * 32 + 16 * (q & 1) + ((tid + k * G::THREADS) >> 6);
-            const int coc = min(co, p.Cout - 1);
+            const int coc = min(round_co(q, k), p.Cout - 1);
             float add = 0.0f;
             if (p.bias && !p.part) add += p.bias[coc];
             if (p.chan_bias && !p.part) add += p.chan_bias[(size_t)ebc * p.chan_bias_stride + coc];
             eadd[q][k] = add;
             const size_t plane = ((size_t)ebc * p.Cout + coc) * HWout;
+            const float* rb = p.residual + plane;
+            if constexpr (SCALAR_PLANE) rb = reinterpret_cast<const float*>(uniform_ptr(rb));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    eres[q][k][i][j] = (p.residual && !p.part) ? p.residual[plane + eoff[i][j]] : 0.0f;
+                for (int j = 0; j < 2; ++j) eres[q][k][i][j] = (p.residual && !p.part) ? rb[eoff[i][j]] : 0.0f;
         }
     }
+    // GroupNorm partials: pixels of this workgroup tile inside the image (the same for every channel and image)
+    const float tile_cnt = (float)(min(2 * TY, p.Hc - oy0) * min(2 * TX, p.Wc - ox0));
+    bool pin[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pin[i][j] = eoy + i < p.Hc && eox + j < p.Wc;
 #pragma unroll
     for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
         const int mt = q >> 1, rbase = 8 * (q & 1);
@@ -563,7 +578,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < EK; ++k) {
-            const int co16 = (tid + k * G::THREADS) >> 6;       // 1024 (channel, tile) pairs per round
+            const int co16 = (tid + k * G::THREADS) >> 6;       // 1024 (channel, tile) pairs per round (LDS row)
             float m[4][4];
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi)
@@ -580,52 +595,46 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
                 y[i][0] = s[i][0] + s[i][1] + s[i][2];
                 y[i][1] = s[i][1] - s[i][2] - s[i][3];
             }
-            const int co = co0 + mt * 32 + 16 * (q & 1) + co16;
+            const int co = round_co(q, k);
             const bool ok = co < p.Cout && eb < p.B;
             const size_t plane = ((size_t)ebc * p.Cout + min(co, p.Cout - 1)) * HWout;
+            float* db = edst + plane;
+            if constexpr (SCALAR_PLANE) db = const_cast<float*>(reinterpret_cast<const float*>(uniform_ptr(db)));
             float vv[2][2];
-            bool in[2][2];
-            float s1 = 0.0f, cnt = 0.0f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     float v = y[i][j] + eadd[q][k] + eres[q][k][i][j];
                     if (p.relu && !p.part) v = fmaxf(v, 0.0f);
-                    in[i][j] = ok && eoy + i < p.Hc && eox + j < p.Wc;
-                    if (in[i][j]) {
-                        edst[plane + eoff[i][j]] = v;
-                        s1 += v;
-                        cnt += 1.0f;
-                    }
+                    if (ok && pin[i][j]) db[eoff[i][j]] = v;
                     vv[i][j] = v;
                 }
             }
             if (p.stats && !p.part) {
-                // One output channel per wave here (co16 is wave-uniform); lanes are the 64 tiles: all of one image
-                // (NIMG == 1) or 16 per image (NIMG == 4).  Per image and workgroup: (count, sum, sum of squared
-                // deviations from this tile's own mean) -- centred partials, merged exactly by gn_finalize_kernel.
+                // One output channel per wave here; lanes are the 64 tiles: all of one image (NIMG == 1) or 16 per
+                // image.  Per image and workgroup: (count, sum, M2).  Single pass with the sums shifted by one of
+                // the tile's own values K (its first pixel, always inside the image): M2 = sum d^2 - (sum d)^2 / n with
+                // d = v - K, exact algebra and free of cancellation because |mean - K| is of the order of the
+                // spread; gn_finalize_kernel merges the partials.
                 const int slots = p.groups_x * p.groups_y, slot = gy * p.groups_x + gx;
-                if (NIMG == 1) {
-                    s1 = wave64_sum(s1);
-                    cnt = wave64_sum(cnt);
-                } else {
-                    s1 = row16_sum(s1);
-                    cnt = row16_sum(cnt);
-                }
-                const float mean_t = s1 / fmaxf(cnt, 1.0f);
-                float m2 = 0.0f;
+                float K;
+                if constexpr (NIMG == 1) K = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv[0][0]), 0));
+                else K = __shfl(vv[0][0], lane & ~(TY * TX - 1));
+                float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const float d = vv[i][j] - mean_t;
-                        if (in[i][j]) m2 += d * d;
+                        const float d = pin[i][j] ? vv[i][j] - K : 0.0f;
+                        s1 += d;
+                        s2 = fmaf(d, d, s2);
                     }
-                m2 = (NIMG == 1) ? wave64_sum(m2) : row16_sum(m2);
+                s1 = (NIMG == 1) ? wave64_sum(s1) : row16_sum(s1);
+                s2 = (NIMG == 1) ? wave64_sum(s2) : row16_sum(s2);
                 if (ok && (et % (TY * TX)) == 0) {
                     float4* dst = reinterpret_cast<float4*>(p.stats) + ((size_t)eb * p.Cout + co) * slots + slot;
-                    *dst = make_float4(cnt, s1, m2, 0.0f);
+                    *dst = make_float4(tile_cnt, fmaf(tile_cnt, K, s1), fmaxf(s2 - s1 * s1 / tile_cnt, 0.0f), 0.0f);
                 }
             }
         }
