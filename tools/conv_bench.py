@@ -49,6 +49,11 @@ LAYERS = [
     # not layers of the network (count 0): per-workgroup cost of a quarter / an eighth of the 8x8 level's channels
     ("probe 64->256 @8 gn+res", 0, 64, 0, 256, 8, 3, 1, 0, 1, 1),
     ("probe 128->256 @8 gn", 0, 128, 0, 256, 8, 3, 1, 0, 1, 0),
+    # fixed cost vs per-chunk cost of the Winograd kernel: one to sixteen 8-channel chunks at 64x64
+    ("probe 8->64 @64 gn+res", 0, 8, 0, 64, 64, 3, 1, 0, 1, 1),
+    ("probe 16->64 @64 gn+res", 0, 16, 0, 64, 64, 3, 1, 0, 1, 1),
+    ("probe 32->64 @64 gn+res", 0, 32, 0, 64, 64, 3, 1, 0, 1, 1),
+    ("probe 128->64 @64 gn+res", 0, 128, 0, 64, 64, 3, 1, 0, 1, 1),
 ]
 
 
