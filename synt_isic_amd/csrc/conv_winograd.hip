@@ -525,6 +525,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         const int w16 = SCALAR_PLANE ? wave_u + k * NW : ((tid + k * G::THREADS) >> 6);
         return co0 + (q >> 1) * 32 + 16 * (q & 1) + w16;
     };
+    // Rows of even length: a thread's two pixels of a row (ox even) are inside or outside together and 8-byte aligned
+    // (planes are 16-byte aligned multiples of the row length), so they move as one float2.  For the clamped
+    // out-of-image tiles eoff[i][0] is then the last pixel of the row: the pair would straddle the row end, so those
+    // lanes read/write nothing through the pair path (pin is false; the residual value read is never used).
+    const bool pair_ok = (p.Wc & 1) == 0 && (eox + 1 < p.Wc);
     float eadd[4][EK], eres[4][EK][2][2];
 #pragma unroll
     for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
@@ -538,10 +543,26 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             const size_t plane = ((size_t)ebc * p.Cout + coc) * HWout;
             const float* rb = p.residual + plane;
             if constexpr (SCALAR_PLANE) rb = reinterpret_cast<const float*>(uniform_ptr(rb));
+            if (p.residual && !p.part) {
+                if (pair_ok) {          // even row length: the thread's two pixels of a row are one aligned float2
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i) {
+                        const float2 t = *reinterpret_cast<const float2*>(rb + eoff[i][0]);
+                        eres[q][k][i][0] = t.x;
+                        eres[q][k][i][1] = t.y;
+                    }
+                } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) eres[q][k][i][j] = (p.residual && !p.part) ? rb[eoff[i][j]] : 0.0f;
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) eres[q][k][i][j] = rb[eoff[i][j]];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) eres[q][k][i][j] = 0.0f;
+            }
         }
     }
     // GroupNorm partials: pixels of this workgroup tile inside the image (the same for every channel and image)
@@ -607,9 +628,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
                 for (int j = 0; j < 2; ++j) {
                     float v = y[i][j] + eadd[q][k] + eres[q][k][i][j];
                     if (p.relu && !p.part) v = fmaxf(v, 0.0f);
-                    if (ok && pin[i][j]) db[eoff[i][j]] = v;
+                    if (!pair_ok && ok && pin[i][j]) db[eoff[i][j]] = v;
                     vv[i][j] = v;
                 }
+                if (pair_ok && ok && pin[i][0]) *reinterpret_cast<float2*>(db + eoff[i][0]) = make_float2(vv[i][0], vv[i][1]);
             }
             if (p.stats && !p.part) {
                 // One output channel per wave here; lanes are the 64 tiles: all of one image (NIMG == 1) or 16 per
