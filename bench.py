@@ -184,8 +184,9 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         roofline = {
-            "kernel": "conv3x3 (52 launches per step: conv_winograd_kernel F(2x2,3x3) + conv_mfma_kernel for 8x8 / stride 2"
-                      " + conv3x3_smallcout_kernel), fp32 on v_mfma_f32_32x32x2_f32",
+            "kernel": "conv3x3 (52 launches per step: conv_winograd_kernel F(2x2,3x3) -- 9-position form for the"
+                      " upsampled inputs, K-split form + splitk_reduce_kernel at 8x8 -- conv_mfma_kernel for stride 2,"
+                      " conv3x3_smallcout_kernel), fp32 on v_mfma_f32_32x32x2_f32",
             "bound": "mfma",
             "achieved": tflops,
             "peak": PEAK_FP32_MFMA_TFLOPS,

@@ -559,8 +559,11 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     // F(2x2,3x3): 16 multiplies per 2x2 outputs and channel pair instead of 36
     SISIC_REQUIRE(a.stats_out == nullptr || conv_stats_slots(a) > 0,
                   "conv2d: stats_out given but sisic_conv_stats_slots() is 0 for these arguments");
+    // matrix FLOPs actually issued: F(2x2,3x3) multiplies 16 positions per 2x2 outputs instead of 36 taps, and only 9
+    // of them for nearest-2x inputs (conv_winograd.hip, upsample form)
+    const bool wino_ups9 = use_wino && a.upsample && !a.gn_scale && winograd_cfg(a) == 66;
     ProfileScope prof(slots_query ? nullptr : ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops,
-                      use_wino ? flops * 16.0 / 36.0 : flops);
+                      use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops);
 
     if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50)) {
         if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)
