@@ -498,7 +498,8 @@ static int winograd_cfg(const sisic_conv_args& a) {
     // the 8x8 level: four images per workgroup and the input channels split four ways keep all CUs busy
     const int Cin = a.c0 + a.c1;
     static const bool ksplit_on = [] { const char* e = std::getenv("SISIC_KSPLIT"); return !e || std::atoi(e) != 0; }();
-    if (ksplit_on && Hout == 8 && Wout == 8 && a.B >= 32 && Cin >= 128 && Cin % 32 == 0 && a.Cout >= 128) return 90;
+    // (no batch-size condition anywhere in this function: an image's bits must not depend on the batch it is in)
+    if (ksplit_on && Hout == 8 && Wout == 8 && Cin >= 128 && Cin % 32 == 0 && a.Cout >= 128) return 90;
     return 0;
 }
 static bool winograd_selected(const sisic_conv_args& a) { return winograd_cfg(a) != 0; }

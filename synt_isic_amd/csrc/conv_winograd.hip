@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             v = v && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
             goff[i] = v ? 4u * (unsigned)((y >> p.ups) * p.Win + (x >> p.ups)) : 0u;
         }
-        gimg[i] = G::PER_IMAGE ? i : (v ? img : 0);
+        gimg[i] = v ? img : 0;       // images past the batch read (and discard) image b0: never an address outside the tensor
         vmask |= (v ? 1u : 0u) << i;
     }
     const bool stage_lane = !G::PER_IMAGE || sl < G::HPI;      // PER_IMAGE: threads past the halo stage nothing

@@ -218,7 +218,7 @@ def test_conv3x3_winograd_ksplit(B, H, W, c0, c1, cout):
     kw = dict(bias=b, x2=x2, relu=True)
     _close(_run_wino(x, w, 90, **kw), _conv_ref(x, w, **kw), tol=3e-5, what="winograd K-split relu")
     d = lambda t: None if t is None else t.to(DEV).contiguous()
-    cfg = 0 if B >= 32 else 90
+    cfg = 0 if (H, W, c0 + c1, cout) == (8, 8, 128, 128) else 90      # the last case is what the auto dispatch picks
     y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 3, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=cfg,
                        w_winograd=ops.pack_winograd_weight(d(w)), with_stats=True)
     _close(y, _conv_ref(x, w, bias=b, x2=x2, residual=res), tol=3e-5, what="winograd K-split + stats")
