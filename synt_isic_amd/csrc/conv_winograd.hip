@@ -225,18 +225,22 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][m][n][r] = 0.0f;
 
-    float rin[G::EPT];            // halo elements in flight (global -> registers -> H_lds)
-    float rw[G::UPT * 4];         // filter slab in flight
-    float gsc = 1.0f, gsh = 0.0f;
-    float gsc_i[G::EPT], gsh_i[G::EPT];      // PER_IMAGE: one GroupNorm pair per image (uniform -> scalar loads)
-    bool cval = false;
-    int hcc = 0;                  // channel of the halo data held in rin
+    struct HaloRegs {             // one chunk's halo elements in flight (global -> registers -> H_lds) and their prologue
+        float v[G::EPT];
+        float gsc = 1.0f, gsh = 0.0f;
+        float gsc_i[G::EPT], gsh_i[G::EPT];      // PER_IMAGE: one GroupNorm pair per image (uniform -> scalar loads)
+        bool cval = false;
+        int hcc = 0;              // channel of the data held in v
+    };
+    struct FilterRegs { float w[G::UPT * 4]; };   // filter slab in flight
+    HaloRegs hr;
+    FilterRegs fr;
 
     // All loads are unconditional at clamped, always-valid addresses and masked afterwards (see conv_mfma.hip).
-    auto load_halo = [&](int chunk) {
+    auto load_halo = [&](int chunk, HaloRegs& h) {
         const int c = (cbase + chunk) * W_CIC + sci;       // scalar
-        cval = c < Cin;
-        hcc = min(c, Cin - 1);
+        h.cval = c < Cin;
+        const int hcc = h.hcc = min(c, Cin - 1);
         const bool first = hcc < p.c0;
         const int csrc = first ? p.c0 : p.c1;
         const char* plane = uniform_ptr(
@@ -245,47 +249,47 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 #pragma unroll
         for (int i = 0; i < G::EPT; ++i) {
             const unsigned vo = (NIMG > 1) ? (unsigned)gimg[i] * img_stride + goff[i] : goff[i];
-            rin[i] = *reinterpret_cast<const float*>(plane + vo);
+            h.v[i] = *reinterpret_cast<const float*>(plane + vo);
         }
         if constexpr (PRO != 0) {
-            gsc = p.gn_scale[b0 * Cin + hcc];              // uniform index: scalar loads.  NIMG > 1: see stage_halo
-            gsh = p.gn_shift[b0 * Cin + hcc];
+            h.gsc = p.gn_scale[b0 * Cin + hcc];            // uniform index: scalar loads.  NIMG > 1: see stage_halo
+            h.gsh = p.gn_shift[b0 * Cin + hcc];
             if constexpr (G::PER_IMAGE) {
 #pragma unroll
                 for (int i = 0; i < G::EPT; ++i) {
                     const int bi = min(b0 + i, p.B - 1);
-                    gsc_i[i] = p.gn_scale[bi * Cin + hcc];
-                    gsh_i[i] = p.gn_shift[bi * Cin + hcc];
+                    h.gsc_i[i] = p.gn_scale[bi * Cin + hcc];
+                    h.gsh_i[i] = p.gn_shift[bi * Cin + hcc];
                 }
             }
         }
     };
     // a thread's float4 of the filter slab always belongs to position (tid >> 4) & 15
     const bool u_active = !UPS || !((WINO_UPS_ZERO >> ((tid >> 4) & 15)) & 1u);
-    auto load_u = [&](int chunk) {
+    auto load_u = [&](int chunk, FilterRegs& f) {
         if (!u_active) return;
         const char* slab = uniform_ptr(p.u + (size_t)(cbase + chunk) * W_CIC * 16 * p.cout_pad + co0);
 #pragma unroll
         for (int i = 0; i < G::UPT; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(slab + uoff[i]);
-            rw[4 * i + 0] = t.x; rw[4 * i + 1] = t.y; rw[4 * i + 2] = t.z; rw[4 * i + 3] = t.w;
+            f.w[4 * i + 0] = t.x; f.w[4 * i + 1] = t.y; f.w[4 * i + 2] = t.z; f.w[4 * i + 3] = t.w;
         }
     };
-    auto stage_halo = [&](int hbuf) {            // registers -> H_lds[hbuf], prologue applied, padding zeroed after it
+    auto stage_halo = [&](int hbuf, const HaloRegs& h) {   // registers -> H_lds[hbuf], prologue applied, padding zeroed after it
         float* dst = H_lds + hbuf * G::HBUF + sci * G::CHS + sl;
-        const unsigned m = cval ? vmask : 0u;
+        const unsigned m = h.cval ? vmask : 0u;
 #pragma unroll
         for (int i = 0; i < G::EPT; ++i) {
-            float v = rin[i];
+            float v = h.v[i];
             if constexpr (PRO != 0) {
-                float sc = gsc, sh = gsh;
+                float sc = h.gsc, sh = h.gsh;
                 if constexpr (G::PER_IMAGE) {
-                    sc = gsc_i[i];
-                    sh = gsh_i[i];
+                    sc = h.gsc_i[i];
+                    sh = h.gsh_i[i];
                 } else if constexpr (NIMG > 1) {
                     const int bi = min(b0 + gimg[i], p.B - 1);
-                    sc = p.gn_scale[(size_t)bi * Cin + hcc];
-                    sh = p.gn_shift[(size_t)bi * Cin + hcc];
+                    sc = p.gn_scale[(size_t)bi * Cin + h.hcc];
+                    sh = p.gn_shift[(size_t)bi * Cin + h.hcc];
                 }
                 v = v * sc + sh;
                 if constexpr (PRO == 2) v = wsilu(v);
@@ -293,13 +297,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             if (stage_lane) dst[i * (G::PER_IMAGE ? G::HPI : G::TPC)] = ((m >> i) & 1u) ? v : 0.0f;
         }
     };
-    auto stage_u = [&](int buf) {
+    auto stage_u = [&](int buf, const FilterRegs& f) {
         if (!u_active) return;
         float* udst = U_lds + buf * W_SLAB + tid * 4;
 #pragma unroll
         for (int i = 0; i < G::UPT; ++i)
             *reinterpret_cast<float4*>(udst + i * G::THREADS * 4) =
-                make_float4(rw[4 * i + 0], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]);
+                make_float4(f.w[4 * i + 0], f.w[4 * i + 1], f.w[4 * i + 2], f.w[4 * i + 3]);
     };
     auto transform = [&](int hbuf, int vbuf, auto xrh_tag) {   // H_lds[hbuf] -> V_lds[vbuf]:  V = B^T d B
         constexpr int xrh = decltype(xrh_tag)::value;      // row half of this wave (NW = 16), fixed per loop instance
@@ -410,20 +414,29 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
 
     // ---- software pipeline over the channel chunks, ONE barrier per chunk.  Entering iteration c:
     //   U/V[c&1] hold chunk c;  H[(c+1)&1] holds the staged halo of chunk c+1;  registers hold halo(c+2) and U(c+1).
-    load_halo(0);
-    load_u(0);
-    stage_halo(0);
-    stage_u(0);
-    if (n > 1) load_halo(1);
-    __syncthreads();
-    if (NW == 16 && (wave & 1)) transform(0, 0, std::integral_constant<int, 1>{});
-    else transform(0, 0, std::integral_constant<int, 0>{});
-    if (n > 1) {
-        stage_halo(1);
-        load_u(1);
+    // Prologue: the loads of chunks 0 AND 1 are issued together (one exposed memory latency instead of two; the
+    // accumulators are not live yet, so the second register set is free here).
+    {
+        HaloRegs h1;
+        FilterRegs f1;
+        load_halo(0, hr);
+        load_u(0, fr);
+        if (n > 1) {
+            load_halo(1, h1);
+            load_u(1, f1);
+        }
+        stage_halo(0, hr);
+        stage_u(0, fr);
+        if (n > 2) load_halo(2, hr);
+        __syncthreads();
+        if (NW == 16 && (wave & 1)) transform(0, 0, std::integral_constant<int, 1>{});
+        else transform(0, 0, std::integral_constant<int, 0>{});
+        if (n > 1) {
+            stage_halo(1, h1);
+            fr = f1;
+        }
+        __syncthreads();
     }
-    if (n > 2) load_halo(2);
-    __syncthreads();
 
     // Phase stagger: all waves of the workgroup run the same program and meet at one barrier per chunk, so left
     // alone they would all be in their staging phase (VALU/LDS) at the same time and all in their MFMA phase at the
@@ -446,20 +459,20 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
                 mfma_chunk(c & 1, role_tag);
 #endif
                 transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
-                stage_u((c + 1) & 1);
-                stage_halo(c & 1);
-                load_halo(c + 3);
-                load_u(c + 2);
+                stage_u((c + 1) & 1, fr);
+                stage_halo(c & 1, hr);
+                load_halo(c + 3, hr);
+                load_u(c + 2, fr);
             } else {
 #if !(WINO_ABLATE & 4)
                 transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
 #endif
-                stage_u((c + 1) & 1);
+                stage_u((c + 1) & 1, fr);
 #if !(WINO_ABLATE & 4)
-                stage_halo(c & 1);               // halo(c+2) -> H[c&1] (its previous content, halo(c), was consumed last iteration)
+                stage_halo(c & 1, hr);               // halo(c+2) -> H[c&1] (its previous content, halo(c), was consumed last iteration)
 #endif
-                load_halo(c + 3);
-                load_u(c + 2);
+                load_halo(c + 3, hr);
+                load_u(c + 2, fr);
 #if !(WINO_ABLATE & 1)
                 mfma_chunk(c & 1, role_tag);
 #endif
@@ -469,11 +482,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         for (; c < n; ++c) {                     // last (up to) three chunks: same order, guarded
             if (c + 1 < n) {
                 transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
-                stage_u((c + 1) & 1);
+                stage_u((c + 1) & 1, fr);
             }
             if (c + 2 < n) {
-                stage_halo(c & 1);
-                load_u(c + 2);
+                stage_halo(c & 1, hr);
+                load_u(c + 2, fr);
             }
 #if !(WINO_ABLATE & 1)
             mfma_chunk(c & 1, role_tag);
