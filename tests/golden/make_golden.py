@@ -13,6 +13,10 @@ drift (torch version, refactors) and give the GPU tests a CPU-independent target
   unet_forward_b2_64.npz    one UNet forward, B=2, 3x64x64, per-sample timesteps
   sample_T50_seed0_64.npz   BASELINE config 1: B=1, 3x64x64, T=50, seed 0: x after steps
                             0, 1, 25, 49 + the final uint8 image
+  sample_T1000_seed3_32.npz the full 1000-step chain of one 3x32x32 image (seed 3): x after steps
+                            0, 99, 499, 899, 999 + the final uint8 image (error accumulation over T=1000)
+  unet_forward_b1_128.npz   one UNet forward at 3x128x128 (BASELINE config 4's resolution: attention
+                            over 1024 and 256 tokens)
 """
 import json
 import os
@@ -76,6 +80,18 @@ def main():
     img, x0, traj = sampler.sample(sd, [0], 50, (64, 64), return_trajectory=True, keep_steps=keep)
     np.savez_compressed(os.path.join(OUT, "sample_T50_seed0_64.npz"), steps=np.array(keep),
                         traj=torch.stack(traj).numpy(), image=img, final=x0.numpy())
+    # the full T=1000 chain at a size the oracle finishes in seconds
+    keep = (0, 99, 499, 899, 999)
+    img, x0, traj = sampler.sample(sd, [3], 1000, (32, 32), return_trajectory=True, keep_steps=keep)
+    np.savez_compressed(os.path.join(OUT, "sample_T1000_seed3_32.npz"), steps=np.array(keep),
+                        traj=torch.stack(traj).numpy(), image=img, final=x0.numpy())
+
+    # BASELINE config 4's resolution
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 3, 128, 128, generator=g)
+    with torch.no_grad():
+        y = unet.unet_forward(sd, x, 321)
+    np.savez_compressed(os.path.join(OUT, "unet_forward_b1_128.npz"), x=x.numpy(), t=np.array(321), y=y.numpy())
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -194,3 +194,18 @@ def test_streamed_noise_equals_materialised_noise(sampler):
         assert torch.equal(torch.cat(got), z)
     finally:
         ns.close()
+
+
+def test_T1000_chain_matches_golden(sampler, golden_dir):
+    """The whole 1000-step chain of one 3x32x32 image against the oracle fixture: error accumulation over T=1000.
+    Stated tolerance: <= 1e-2 in [-1,1] at the end, uint8 within 1 LSB on >= 99 % of pixels."""
+    g = np.load(os.path.join(golden_dir, "sample_T1000_seed3_32.npz"))
+    res = sampler.generate_seeds("NV", [3], T=1000, size=(32, 32), return_trajectory=True)
+    assert res.steps_done == 1000 and res.timesteps[0] == 999 and res.timesteps[-1] == 0
+    traj = res.trajectory.cpu().numpy()
+    for i, step in enumerate(g["steps"]):
+        err = np.abs(traj[int(step)] - g["traj"][i]).max()
+        assert err <= 1e-2, f"step {step}: {err:.3e}"
+    assert np.abs(res.latents.cpu().numpy() - g["final"]).max() <= 1e-2
+    img = res.images.cpu().numpy()
+    assert np.mean(np.abs(img.astype(int) - g["image"].astype(int)) <= 1) >= 0.99

@@ -53,6 +53,13 @@ def test_forward_matches_golden_and_oracle(model, golden_dir, synthetic_sd):
     assert (out.cpu() - ref).abs().max().item() <= FWD_TOL
 
 
+def test_forward_128_matches_golden(model, golden_dir):
+    """BASELINE config 4's resolution (3x128x128): attention over 1024 and 256 tokens, five 64-row tile rounds."""
+    g = np.load(os.path.join(golden_dir, "unet_forward_b1_128.npz"))
+    y = model(torch.from_numpy(g["x"]).to(DEV), int(g["t"])).sample.cpu().numpy()
+    assert np.abs(y - g["y"]).max() <= FWD_TOL
+
+
 def test_timestep_argument_forms(model, synthetic_sd):
     """model(latents, t): t is a 0-dim int64 tensor from scheduler.timesteps (image_generator.py:395-400);
     XAI.py:805-807 passes t.unsqueeze(0); an int must work too."""

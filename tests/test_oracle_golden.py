@@ -45,3 +45,31 @@ def test_forward_is_batch_independent(synthetic_sd):
         full = unet.unet_forward(synthetic_sd, x, 100)
         one = unet.unet_forward(synthetic_sd, x[1:2], 100)
     torch.testing.assert_close(full[1:2], one, rtol=0, atol=1e-5)
+
+
+def test_unet_forward_128_golden(golden_dir, synthetic_sd):
+    """BASELINE config 4's resolution: attention over 1024 (32x32) and 256 (16x16) tokens."""
+    g = np.load(os.path.join(golden_dir, "unet_forward_b1_128.npz"))
+    with torch.no_grad():
+        y = unet.unet_forward(synthetic_sd, torch.from_numpy(g["x"]), int(g["t"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=0, atol=2e-5)
+
+
+def test_sample_T1000_golden_prefix(golden_dir, synthetic_sd):
+    """The 1000-step fixture, replayed for its first 100 steps on the CPU path (the whole chain is replayed by the GPU
+    test; here it would take the larger part of a minute)."""
+    from oracle import ddpm
+    g = np.load(os.path.join(golden_dir, "sample_T1000_seed3_32.npz"))
+    assert [int(s) for s in g["steps"]] == [0, 99, 499, 899, 999]
+    sched = ddpm.DDPMSchedulerOracle()
+    sched.set_timesteps(1000)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, 32, 32, generator=gen)
+    with torch.no_grad():
+        for i, t in enumerate(sched.timesteps[:100]):
+            eps = unet.unet_forward(synthetic_sd, x, int(t))
+            z = torch.randn(1, 3, 32, 32, generator=gen)
+            x = sched.step(eps, int(t), x, noise=z)
+            if i == 0:
+                np.testing.assert_allclose(x.numpy(), g["traj"][0], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(x.numpy(), g["traj"][1], rtol=0, atol=5e-4)
