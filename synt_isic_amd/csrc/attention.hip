@@ -52,7 +52,8 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
     const float* Kp = Qp + (size_t)C * N;
     const float* Vp = Kp + (size_t)C * N;
 
-    // the softmax scale is folded into q once, so the score tile needs no multiply
+    // the softmax scale AND log2(e) are folded into q once: the score tile needs no multiply and p = 2^(s - m) is a bare
+    // v_exp_f32 (softmax is invariant under the common base change)
     float qreg[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qreg[s] = (q < N) ? Qp[(size_t)(2 * s + half) * N + q] * scale : 0.0f;
@@ -88,7 +89,7 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);     // first tile: exp(-inf) = 0; unchanged maximum: 1
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first tile: 2^(-inf) = 0; unchanged maximum: 1
         l_part *= alpha;
 #pragma unroll
         for (int d = 0; d < ATT_D / 2; ++d) o2[d] *= alpha;
@@ -97,7 +98,7 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
         for (int rq = 0; rq < 4; ++rq) {
             float pv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pv[i] = __expf(S[4 * rq + i] - m_new);   // masked keys: exp(-inf) = 0
+            for (int i = 0; i < 4; ++i) pv[i] = __builtin_amdgcn_exp2f(S[4 * rq + i] - m_new);   // masked keys: 2^(-inf) = 0
             l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
             const int koff = kt * 32 + 8 * rq + 4 * half;
 #pragma unroll
@@ -170,7 +171,7 @@ int launch_attention(sisic_ctx* ctx, const float* qkv, float* out, int B, int C,
     const int64_t grid = (int64_t)B * heads * q_blocks;
     SISIC_REQUIRE(grid < (int64_t(1) << 31), "attention: grid too large");
     ProfileScope prof(ctx, s, PK_ATTN, 16.0 * B * C * N, 4.0 * B * C * double(N) * N);
-    const float scale = 1.0f / sqrtf((float)head_dim);
+    const float scale = 1.4426950408889634f / sqrtf((float)head_dim);     // head_dim^-1/2 * log2(e)
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads,
                        q_blocks, scale);
     SISIC_HIP(hipGetLastError());
