@@ -96,7 +96,8 @@ int sisic_destroy(sisic_ctx* ctx) {
     if (!ctx) return SISIC_OK;
     (void)profile_collect(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    if (ctx->splitk) (void)hipFree(ctx->splitk);
+    for (auto& kv : ctx->splitk)
+        if (kv.second.p) (void)hipFree(kv.second.p);
     delete ctx;
     return SISIC_OK;
 }

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sisic.h"
@@ -60,8 +62,11 @@ struct sisic_ctx {
     sisic::ProfileSlot prof[sisic::PK_COUNT];
     std::vector<sisic::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;
-    float* splitk = nullptr;        // partial outputs of K-split convolutions (conv_winograd.hip), grown on demand
-    size_t splitk_floats = 0;
+    // partial outputs of K-split convolutions (conv_winograd.hip): one scratch buffer per stream, grown on demand, so
+    // that models sampling concurrently on different streams of this context never share it
+    struct SplitK { float* p = nullptr; size_t floats = 0; };
+    std::map<hipStream_t, SplitK> splitk;
+    std::mutex splitk_mutex;
 };
 
 namespace sisic {

@@ -841,17 +841,23 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         SISIC_REQUIRE(HW <= 256 && (cdiv(a.c0 + a.c1, W_CIC) % K) == 0,
                       "conv2d(winograd K-split): needs <= 256 output pixels per image and a multiple of %d input channels", K * W_CIC);
         const size_t need = (size_t)K * planes * HW;
-        if (ctx->splitk_floats < need) {
-            SISIC_HIP(hipStreamSynchronize(s));
-            if (ctx->splitk) SISIC_HIP(hipFree(ctx->splitk));
-            ctx->splitk = nullptr; ctx->splitk_floats = 0;
-            SISIC_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->splitk), need * sizeof(float)));
-            ctx->splitk_floats = need;
+        float* scratch = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(ctx->splitk_mutex);
+            auto& buf = ctx->splitk[s];
+            if (buf.floats < need) {
+                SISIC_HIP(hipStreamSynchronize(s));          // earlier launches on this stream may still read the old buffer
+                if (buf.p) SISIC_HIP(hipFree(buf.p));
+                buf.p = nullptr; buf.floats = 0;
+                SISIC_HIP(hipMalloc(reinterpret_cast<void**>(&buf.p), need * sizeof(float)));
+                buf.floats = need;
+            }
+            scratch = buf.p;
         }
         p.ksplit = K;
-        p.part = ctx->splitk;
+        p.part = scratch;
         SISIC_TRY((launch_wino_pro<4, 4, 4, 16>(ctx, p, s)));
-        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, ctx->splitk,
+        hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, scratch,
                            (int)planes, (int)HW, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu,
                            a.out, a.stats_out);
         SISIC_HIP(hipGetLastError());
