@@ -495,11 +495,12 @@ static int winograd_cfg(const sisic_conv_args& a) {
     const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
     if (!fits32) return 0;
     if (Hout >= 12 && Wout >= 12) return 66;
-    // the 8x8 level: four images per workgroup and the input channels split four ways keep all CUs busy
+    // the 8x8 level (and the classifier's 7x7): four images per workgroup and the input channels split four ways
+    // keep all CUs busy
     const int Cin = a.c0 + a.c1;
     static const bool ksplit_on = [] { const char* e = std::getenv("SISIC_KSPLIT"); return !e || std::atoi(e) != 0; }();
     // (no batch-size condition anywhere in this function: an image's bits must not depend on the batch it is in)
-    if (ksplit_on && Hout == 8 && Wout == 8 && Cin >= 128 && Cin % 32 == 0 && a.Cout >= 128) return 90;
+    if (ksplit_on && Hout <= 8 && Wout <= 8 && Hout >= 5 && Wout >= 5 && Cin >= 128 && Cin % 32 == 0 && a.Cout >= 128) return 90;
     return 0;
 }
 static bool winograd_selected(const sisic_conv_args& a) { return winograd_cfg(a) != 0; }

@@ -21,6 +21,7 @@ struct FoldedConv {
     int w_idx = -1;
     int bn_w = -1, bn_b = -1, bn_m = -1, bn_v = -1;
     float* packed = nullptr;
+    float* wino = nullptr;           // Winograd-domain filters of the BN-folded weight (3x3 stride 1 only)
     float* bias = nullptr;
 };
 
@@ -123,6 +124,10 @@ int fold(sisic_resnet* r, FoldedConv& c) {
     SISIC_HIP(hipMemcpy(raw, wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
     SISIC_TRY(dev_alloc(r, (size_t)sisic_conv_packed_numel(c.cout, c.cin, c.k), &c.packed));
     SISIC_TRY(launch_conv_pack(r->ctx, raw, c.cout, c.cin, c.k, c.packed, nullptr));
+    if (c.k == 3 && c.stride == 1) {     // F(2x2,3x3) for the 13 stride-1 3x3 convolutions (conv_winograd.hip)
+        SISIC_TRY(dev_alloc(r, (size_t)winograd_packed_numel(c.cout, c.cin), &c.wino));
+        SISIC_TRY(launch_winograd_pack(r->ctx, raw, c.cout, c.cin, c.wino, nullptr));
+    }
     SISIC_TRY(dev_alloc(r, c.cout, &c.bias));
     SISIC_HIP(hipMemcpy(c.bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
     return SISIC_OK;
@@ -150,6 +155,7 @@ int run_conv(sisic_resnet* r, const FoldedConv& c, const float* in, int B, int H
     a.in0 = in; a.c0 = c.cin; a.B = B; a.Hin = H; a.Win = W;
     a.ksize = c.k; a.stride = c.stride;
     a.w_packed = c.packed; a.bias = c.bias; a.Cout = c.cout;
+    a.w_winograd = c.wino;
     a.residual = residual; a.relu = relu ? 1 : 0; a.out = out;
     return launch_conv2d(r->ctx, a, s);
 }

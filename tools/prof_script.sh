@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 per-kernel statistics of any python script of this repo; run on the GPU box from the repo root:
+#   bash tools/prof_script.sh <tag> tools/bench_configs.py [args...]     -> gpurun_out/<tag>_kernel_stats.csv
+set -e
+tag=$1; script=$2; shift 2
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p "$root/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_$tag
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- \
+    python3 "$root/$script" "$@" > "$root/gpurun_out/${tag}_prof.log" 2>&1
+f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
+test -n "$f"
+cp "$f" "$root/gpurun_out/${tag}_kernel_stats.csv"
+cut -c1-170 "$f" | sed -n 1,22p
