@@ -2,9 +2,12 @@
 //
 // On the MFMA kernel a 3-channel output pads to a 64-row tile (95 % of the matrix work wasted; 160 us at
 // B=64, 64x64).  With so few outputs the layer is bandwidth/LDS-bound (14 MFLOP per image against 1 MB of
-// input), so it runs on the vector ALU instead: one thread per output pixel of a 16x16 tile, the input halo
-// tile staged through LDS exactly like conv_mfma.hip (GroupNorm+SiLU prologue on the way in, zero padding
-// after it, two-source concat), the <=4 filters of a tap read as one broadcast ds_read_b128.
+// input), so it runs on the vector ALU instead.  A thread owns FOUR horizontally adjacent output pixels of a
+// 32x32 tile: the six input values of a row it needs are one ds_read_b128 + one ds_read_b64 and are reused by
+// the 3 taps x 4 pixels x 4 filters that touch them (a pixel per thread re-read every input nine times and was
+// LDS-bound at 87 us); the <=4 filters of a tap are one broadcast ds_read_b128.  The input halo tile is staged
+// through LDS exactly like conv_mfma.hip (GroupNorm+SiLU prologue on the way in, zero padding after it,
+// two-source concat), two channels per chunk so that a staging thread moves ten elements.
 // Same packed weight layout as conv_mfma.hip ([Cin_pad][9][Cout_pad]): the first 4 floats of each row.
 //
 // Algorithmic bytes: 4*B*(Cin + Cout)*H*W (+ weights); HBM-bound.
@@ -12,11 +15,14 @@
 
 namespace sisic {
 
-constexpr int CS_TW = 16, CS_TH = 16, CS_CIC = 8, CS_THR = 256;
+constexpr int CS_TW = 32, CS_TH = 32, CS_PX = 4, CS_CIC = 2, CS_THR = (CS_TW / CS_PX) * CS_TH;   // 256 threads
 constexpr int CS_IW = CS_TW + 2, CS_IH = CS_TH + 2;
-constexpr int CS_TPC = CS_THR / CS_CIC;                          // 32 threads stage one channel
-constexpr int CS_EPT = (CS_IH * CS_IW + CS_TPC - 1) / CS_TPC;    // 11
-constexpr int CS_CHS = CS_EPT * CS_TPC;                          // 352 floats per channel (padded)
+constexpr int CS_IWP = 36;                                       // LDS row stride: float4-aligned rows
+constexpr int CS_TPC = CS_THR / CS_CIC;                          // 128 threads stage one channel
+constexpr int CS_EPT = (CS_IH * CS_IWP + CS_TPC - 1) / CS_TPC;   // 10
+constexpr int CS_CHS = CS_EPT * CS_TPC;                          // 1280 floats per channel (padded)
+static_assert(CS_IWP >= CS_IW + 2 && CS_IWP % 4 == 0 && CS_CHS % 4 == 0, "aligned rows");
+static_assert(CS_CIC * 9 <= CS_THR, "one thread per filter row");
 
 struct ConvSmallParams {
     const float* in0;
@@ -37,7 +43,7 @@ struct ConvSmallParams {
     int tiles_x, tiles_y, nchunks;
 };
 
-__global__ void __launch_bounds__(CS_THR) conv3x3_smallcout_kernel(const ConvSmallParams p) {
+__global__ void __launch_bounds__(CS_THR, 3) conv3x3_smallcout_kernel(const ConvSmallParams p) {
     __shared__ __attribute__((aligned(16))) float in_lds[2][CS_CIC * CS_CHS];
     __shared__ __attribute__((aligned(16))) float w_lds[2][CS_CIC * 9 * 4];
 
@@ -56,9 +62,10 @@ __global__ void __launch_bounds__(CS_THR) conv3x3_smallcout_kernel(const ConvSma
     unsigned vmask = 0;
 #pragma unroll
     for (int i = 0; i < CS_EPT; ++i) {
-        const int e = sl + i * CS_TPC;
-        const int gy = oy0 - 1 + e / CS_IW, gx = ox0 - 1 + e % CS_IW;
-        const bool v = e < CS_IH * CS_IW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int e = sl + i * CS_TPC;                       // position in the padded [CS_IH][CS_IWP] halo tile
+        const int yy = e / CS_IWP, xx = e % CS_IWP;
+        const int gy = oy0 - 1 + yy, gx = ox0 - 1 + xx;
+        const bool v = yy < CS_IH && xx < CS_IW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         goff[i] = v ? gy * p.W + gx : 0;
         vmask |= (v ? 1u : 0u) << i;
     }
@@ -79,7 +86,7 @@ __global__ void __launch_bounds__(CS_THR) conv3x3_smallcout_kernel(const ConvSma
             gsc = p.gn_scale[(size_t)b * Cin + cc];
             gsh = p.gn_shift[(size_t)b * Cin + cc];
         }
-        // 72 rows (ci, tap) x 4 filters per chunk: threads 0..71 fetch one float4 each
+        // 18 rows (ci, tap) x 4 filters per chunk: threads 0..17 fetch one float4 each
         const int row = min(tid, CS_CIC * 9 - 1);
         const float4 t = *reinterpret_cast<const float4*>(p.w + ((size_t)chunk * CS_CIC * 9 + row) * p.cout_pad);
         rw[0] = t.x; rw[1] = t.y; rw[2] = t.z; rw[3] = t.w;
@@ -97,8 +104,12 @@ __global__ void __launch_bounds__(CS_THR) conv3x3_smallcout_kernel(const ConvSma
         if (tid < CS_CIC * 9) *reinterpret_cast<float4*>(&w_lds[buf][tid * 4]) = make_float4(rw[0], rw[1], rw[2], rw[3]);
     };
 
-    const int py = tid / CS_TW, px = tid % CS_TW;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int py = tid / (CS_TW / CS_PX), px0 = (tid % (CS_TW / CS_PX)) * CS_PX;
+    float acc[CS_PX][4];
+#pragma unroll
+    for (int q = 0; q < CS_PX; ++q)
+#pragma unroll
+        for (int co = 0; co < 4; ++co) acc[q][co] = 0.0f;
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
@@ -106,17 +117,24 @@ __global__ void __launch_bounds__(CS_THR) conv3x3_smallcout_kernel(const ConvSma
         const int buf = chunk & 1;
         const bool more = chunk + 1 < p.nchunks;
         if (more) load_chunk(chunk + 1);
-        const float* I = &in_lds[buf][py * CS_IW + px];
+        const float* I = &in_lds[buf][py * CS_IWP + px0];
         const float* Wt = &w_lds[buf][0];
-#pragma unroll
-        for (int ci = 0; ci < CS_CIC; ++ci) {
+#pragma unroll 1
+        for (int ci = 0; ci < CS_CIC; ++ci) {             // not unrolled: 18 taps' filters in flight would cost 72 registers
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
+                const float* row = I + ci * CS_CHS + ky * CS_IWP;
+                const float4 r4 = *reinterpret_cast<const float4*>(row);           // halo columns px0 .. px0+3
+                const float2 r2 = *reinterpret_cast<const float2*>(row + 4);       //              px0+4, px0+5
+                const float in[6] = {r4.x, r4.y, r4.z, r4.w, r2.x, r2.y};
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float a = I[ci * CS_CHS + ky * CS_IW + kx];
                     const float4 w4 = *reinterpret_cast<const float4*>(&Wt[(ci * 9 + ky * 3 + kx) * 4]);
-                    acc[0] += a * w4.x; acc[1] += a * w4.y; acc[2] += a * w4.z; acc[3] += a * w4.w;
+#pragma unroll
+                    for (int q = 0; q < CS_PX; ++q) {
+                        const float a = in[q + kx];
+                        acc[q][0] += a * w4.x; acc[q][1] += a * w4.y; acc[q][2] += a * w4.z; acc[q][3] += a * w4.w;
+                    }
                 }
             }
         }
@@ -124,18 +142,30 @@ __global__ void __launch_bounds__(CS_THR) conv3x3_smallcout_kernel(const ConvSma
         __syncthreads();
     }
 
-    const int oy = oy0 + py, ox = ox0 + px;
-    if (oy < p.H && ox < p.W) {
+    const int oy = oy0 + py, ox = ox0 + px0;
+    if (oy < p.H) {
+        const bool vec = (p.W & 3) == 0;           // then rows and planes are float4-aligned and ox % 4 == 0
 #pragma unroll
         for (int co = 0; co < 4; ++co) {
             if (co < p.Cout) {
-                const size_t idx = ((size_t)b * p.Cout + co) * HW + (size_t)oy * p.W + ox;
-                float v = acc[co];
-                if (p.bias) v += p.bias[co];
-                if (p.chan_bias) v += p.chan_bias[(size_t)b * p.chan_bias_stride + co];
-                if (p.residual) v += p.residual[idx];
-                if (p.relu) v = fmaxf(v, 0.0f);
-                p.out[idx] = v;
+                const size_t base = ((size_t)b * p.Cout + co) * HW + (size_t)oy * p.W;
+                float add = 0.0f;
+                if (p.bias) add += p.bias[co];
+                if (p.chan_bias) add += p.chan_bias[(size_t)b * p.chan_bias_stride + co];
+                float v[CS_PX];
+#pragma unroll
+                for (int q = 0; q < CS_PX; ++q) {
+                    v[q] = acc[q][co] + add;
+                    if (p.residual && ox + q < p.W) v[q] += p.residual[base + ox + q];
+                    if (p.relu) v[q] = fmaxf(v[q], 0.0f);
+                }
+                if (vec) {
+                    if (ox < p.W) *reinterpret_cast<float4*>(p.out + base + ox) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < CS_PX; ++q)
+                        if (ox + q < p.W) p.out[base + ox + q] = v[q];
+                }
             }
         }
     }
