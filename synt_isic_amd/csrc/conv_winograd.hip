@@ -24,6 +24,21 @@
 
 // Timing-only ablation builds for tools/conv_bench.py (results are wrong): bit 0 skips the MFMAs, bit 1 the
 // output transform, bit 2 the halo staging + input transform.  Never defined in the shipped library.
+// WINO_TIMING (diagnostic build only, never in the shipped library): wave 0 of every workgroup stamps s_memtime at its
+// phase boundaries into p.stats ([nwg][8] uint64) instead of the GroupNorm partials -- tools/wino_phases.py reads them.
+#ifndef WINO_TIMING
+#define WINO_TIMING 0
+#endif
+#if WINO_TIMING
+#define WINO_STAMP(slot)                                                                                   \
+    do {                                                                                                   \
+        unsigned long long t_;                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
+        if (tid == 0) reinterpret_cast<unsigned long long*>(p.stats)[(size_t)blockIdx.x * 8 + (slot)] = t_; \
+    } while (0)
+#else
+#define WINO_STAMP(slot) do { } while (0)
+#endif
 #ifndef WINO_ABLATE
 #define WINO_ABLATE 0
 #endif
@@ -160,6 +175,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     const int wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int HWin = p.Hin * p.Win, Cin = p.c0 + p.c1;
+    WINO_STAMP(0);
 
     // ---- halo staging plan: TPC threads per channel of the chunk.  The staged channel is wave-uniform
     // (TPC is a multiple of 64), which lets every chunk-dependent address term live in SGPRs: global loads take the
@@ -416,6 +432,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     //   U/V[c&1] hold chunk c;  H[(c+1)&1] holds the staged halo of chunk c+1;  registers hold halo(c+2) and U(c+1).
     // Prologue: the loads of chunks 0 AND 1 are issued together (one exposed memory latency instead of two; the
     // accumulators are not live yet, so the second register set is free here).
+    WINO_STAMP(1);               // index plans done
     {
         HaloRegs h1;
         FilterRegs f1;
@@ -429,6 +446,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         stage_u(0, fr);
         if (n > 2) load_halo(2, hr);
         __syncthreads();
+        WINO_STAMP(2);           // first chunk loaded and staged
         if (NW == 16 && (wave & 1)) transform(0, 0, std::integral_constant<int, 1>{});
         else transform(0, 0, std::integral_constant<int, 0>{});
         if (n > 1) {
@@ -437,6 +455,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         }
         __syncthreads();
     }
+    WINO_STAMP(3);               // prologue done
 
     // Phase stagger: all waves of the workgroup run the same program and meet at one barrier per chunk, so left
     // alone they would all be in their staging phase (VALU/LDS) at the same time and all in their MFMA phase at the
@@ -514,6 +533,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         by_half(std::integral_constant<int, 0>{});
     }
 
+    WINO_STAMP(4);               // channel loop done
     // ---- output transform: four rounds of 16 output channels through LDS.  Bias, time-embedding and
     // residual operands of all four rounds are fetched up front so their latency is paid once, under
     // the first round's LDS traffic, rather than once per round behind a barrier.
@@ -585,6 +605,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) pin[i][j] = eoy + i < p.Hc && eox + j < p.Wc;
+    WINO_STAMP(5);               // epilogue operands requested
 #pragma unroll
     for (int q = 0; q < ((WINO_ABLATE & 2) ? 0 : 4); ++q) {
         const int mt = q >> 1, rbase = 8 * (q & 1);
@@ -646,7 +667,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
                 }
                 if (pair_ok && ok && pin[i][0]) *reinterpret_cast<float2*>(db + eoff[i][0]) = make_float2(vv[i][0], vv[i][1]);
             }
-            if (p.stats && !p.part) {
+            if (!WINO_TIMING && p.stats && !p.part) {
                 // One output channel per wave here; lanes are the 64 tiles: all of one image (NIMG == 1) or 16 per
                 // image.  Per image and workgroup: (count, sum, M2).  Single pass with the sums shifted by one of
                 // the tile's own values K (its first pixel, always inside the image): M2 = sum d^2 - (sum d)^2 / n with
@@ -675,6 +696,11 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         }
         __syncthreads();
     }
+    WINO_STAMP(6);               // output transform issued
+#if WINO_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WINO_STAMP(7);               // stores retired
+#endif
 }
 
 // U = G g G^T per (co, ci), float64 arithmetic, written as [Cin_pad][16][cout_pad] (zero padded)
