@@ -471,32 +471,43 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     // Every instance executes the same barriers.
     auto channel_loop = [&](auto role_tag, auto first_tag, auto xrh_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        int c = 0;
-        for (; c + 3 < n; ++c) {                 // steady state: one basic block per chunk
+        // One chunk of the steady state; PAR = c & 1 is a compile-time constant (the loop is unrolled by two), so every
+        // LDS buffer offset is an instruction immediate instead of a per-use address addition.
+        auto body = [&](const int c, auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
             if constexpr (FIRST) {
 #if !(WINO_ABLATE & 1)
-                mfma_chunk(c & 1, role_tag);
+                mfma_chunk(PAR, role_tag);
 #endif
-                transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
-                stage_u((c + 1) & 1, fr);
-                stage_halo(c & 1, hr);
+                transform(PAR ^ 1, PAR ^ 1, xrh_tag);
+                stage_u(PAR ^ 1, fr);
+                stage_halo(PAR, hr);
                 load_halo(c + 3, hr);
                 load_u(c + 2, fr);
             } else {
 #if !(WINO_ABLATE & 4)
-                transform((c + 1) & 1, (c + 1) & 1, xrh_tag);
+                transform(PAR ^ 1, PAR ^ 1, xrh_tag);
 #endif
-                stage_u((c + 1) & 1, fr);
+                stage_u(PAR ^ 1, fr);
 #if !(WINO_ABLATE & 4)
-                stage_halo(c & 1, hr);               // halo(c+2) -> H[c&1] (its previous content, halo(c), was consumed last iteration)
+                stage_halo(PAR, hr);                 // halo(c+2) -> H[c&1] (its previous content, halo(c), was consumed last iteration)
 #endif
                 load_halo(c + 3, hr);
                 load_u(c + 2, fr);
 #if !(WINO_ABLATE & 1)
-                mfma_chunk(c & 1, role_tag);
+                mfma_chunk(PAR, role_tag);
 #endif
             }
             __syncthreads();
+        };
+        int c = 0;
+        for (; c + 4 < n; c += 2) {              // steady state, two chunks per trip: one basic block
+            body(c, std::integral_constant<int, 0>{});
+            body(c + 1, std::integral_constant<int, 1>{});
+        }
+        if (c + 3 < n) {                         // odd leftover of the steady state
+            body(c, std::integral_constant<int, 0>{});
+            ++c;
         }
         for (; c < n; ++c) {                     // last (up to) three chunks: same order, guarded
             if (c + 1 < n) {
