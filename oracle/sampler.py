@@ -74,6 +74,23 @@ def denormalize_to_uint8(x: torch.Tensor) -> np.ndarray:
     return (img.cpu().numpy() * 255).astype(np.uint8)
 
 
+def color_postprocess(image: np.ndarray, stats: Optional[dict]) -> np.ndarray:
+    """image_generator.py:502-545 for one uint8 [H,W,3] image: per-channel mean/std matching towards the class
+    statistics (``color_statistics.json`` entry ``{"rgb": {"mean": [...], "std": [...]}}``) with the scale clipped
+    to [0.6, 1.4], blended 35 % into the original, clipped to [0,255] and truncated to uint8.  An absent class entry or
+    an entry without rgb.mean leaves the image untouched."""
+    if not stats or "rgb" not in stats or "mean" not in stats["rgb"]:
+        return image
+    target_mean = np.array(stats["rgb"].get("mean", [128, 128, 128]), dtype=np.float32)
+    target_std = np.array(stats["rgb"].get("std", [50, 50, 50]), dtype=np.float32)
+    cur_mean = np.mean(image, axis=(0, 1)).astype(np.float32)
+    cur_std = np.std(image, axis=(0, 1)).astype(np.float32)
+    scale = np.clip(target_std / np.maximum(cur_std, 1e-6), 0.6, 1.4)
+    shifted = (image.astype(np.float32) - cur_mean) * scale + target_mean
+    out = 0.35 * shifted + (1.0 - 0.35) * image.astype(np.float32)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 @torch.no_grad()
 def sample(sd: Dict[str, torch.Tensor], seeds: Sequence[int], T: int, size: Tuple[int, int] = (64, 64),
            beta_schedule: str = "squaredcos_cap_v2", return_trajectory: bool = False,

@@ -236,6 +236,34 @@ def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch
                         steps_done=done_total)
 
 
+COLOR_BLEND = 0.35            # image_generator.py:532 "alpha"
+COLOR_SCALE_CLIP = (0.6, 1.4)  # image_generator.py:527
+
+
+def apply_color_statistics(images: np.ndarray, stats: Optional[dict]) -> np.ndarray:
+    """Colour post-processing of the GUI path (``ImageGenerator._apply_color_postprocessing``,
+    image_generator.py:502-545) for a batch of uint8 [B,H,W,3] images: each image's per-channel mean and standard
+    deviation are pulled towards the class statistics of ``color_statistics.json`` -- scale clipped to [0.6, 1.4],
+    35 % blend with the original, clip to [0,255], truncation to uint8.  Host-side numpy in the reference's float32
+    operation order (bit-identical results); images are processed one by one because the reference's statistics are
+    per image.  ``stats`` = the JSON entry of the class, or None / incomplete: images are returned unchanged."""
+    if not stats or "rgb" not in stats or "mean" not in stats["rgb"]:
+        return images
+    t_mean = np.asarray(stats["rgb"].get("mean", [128, 128, 128]), dtype=np.float32)
+    t_std = np.asarray(stats["rgb"].get("std", [50, 50, 50]), dtype=np.float32)
+    out = np.empty_like(images)
+    for b in range(images.shape[0]):
+        img = images[b]
+        mean = img.mean(axis=(0, 1)).astype(np.float32)             # float64 accumulation, then float32 like the reference
+        std = img.std(axis=(0, 1)).astype(np.float32)
+        scale = np.clip(t_std / np.maximum(std, 1e-6), *COLOR_SCALE_CLIP)
+        f = img.astype(np.float32)
+        moved = (f - mean) * scale + t_mean
+        mixed = COLOR_BLEND * moved + (1.0 - COLOR_BLEND) * f
+        out[b] = np.clip(mixed, 0, 255).astype(np.uint8)
+    return out
+
+
 class Sampler:
     """Holds one loaded UNet per class, like ``ModelManager.loaded_models`` (model_manager.py:19-171)."""
 
@@ -245,6 +273,18 @@ class Sampler:
         self.models: Dict[str, HipUNet2DModel] = {}
         self.cancel = C.c_int(0)          # cooperative stop flag (image_generator.py:320,396)
         self.noise_segment_steps = 64     # steps of noise drawn and uploaded per pipeline stage (NoiseStream)
+        self.color_statistics: Dict[str, dict] = {}   # class -> color_statistics.json entry (image_generator.py:142-170)
+
+    def load_color_statistics(self, path: str) -> int:
+        """``checkpoints/color_statistics.json`` (image_generator.py:142-170); returns the number of classes read.
+        A missing file leaves post-processing a no-op, as in the reference."""
+        import json
+        import os as _os
+        if not _os.path.exists(path):
+            return 0
+        with open(path, "r") as f:
+            self.color_statistics = json.load(f)
+        return len(self.color_statistics)
 
     def add_model(self, class_name: str, state_dict: Dict[str, torch.Tensor], **unet_kwargs) -> HipUNet2DModel:
         m = HipUNet2DModel(**unet_kwargs)
@@ -286,12 +326,14 @@ class Sampler:
         return res
 
     def generate(self, seed: int, class_name: str, T: int, *, count: int = 1, size: Tuple[int, int] = (128, 128),
-                 return_trajectory: bool = False, seed_is_base: bool = False):
+                 return_trajectory: bool = False, seed_is_base: bool = False, postprocess: bool = False):
         """``generate(seed, class, T)``: returns (uint8 [count,H,W,3] numpy, trajectory list | None).
 
         seed_is_base=False: image i uses ``manual_seed(seed + i)`` directly (the literal call);
         seed_is_base=True: ``seed`` is the GUI's base seed and image i uses
         ``(seed + md5_offset(class) + i) & 0x7fffffff`` (image_generator.py:626-631).
+        postprocess=True applies the class colour statistics (``load_color_statistics``) to the uint8 images like
+        ``generate_single_image(..., postprocess=True)`` does before saving (image_generator.py:449-452).
         Always returns a tuple (the reference's bare ``return False`` on early exit is a latent bug).
         """
         if seed_is_base:
@@ -300,6 +342,8 @@ class Sampler:
             seeds = [(int(seed) + i) & 0x7FFFFFFF for i in range(count)]
         res = self.generate_seeds(class_name, seeds, T, size, return_trajectory)
         images = res.images.cpu().numpy()
+        if postprocess:
+            images = apply_color_statistics(images, self.color_statistics.get(class_name))
         traj = None
         if return_trajectory:
             # list of per-step (B,3,H,W) tensors, the shape xai_integration.py consumes

@@ -209,3 +209,23 @@ def test_T1000_chain_matches_golden(sampler, golden_dir):
     assert np.abs(res.latents.cpu().numpy() - g["final"]).max() <= 1e-2
     img = res.images.cpu().numpy()
     assert np.mean(np.abs(img.astype(int) - g["image"].astype(int)) <= 1) >= 0.99
+
+
+def test_generate_postprocess_and_pth_round_trip(sampler, synthetic_sd, tmp_path):
+    """a checkpoint written as the reference's `unet_{CLASS}_best.pth` (torch.save of the
+    diffusers-keyed state dict) loads through torch.load + load_state_dict, and generate(postprocess=True) applies the
+    class colour statistics to the same images (image_generator.py:449-452, 502-545)."""
+    from synt_isic_amd.sampler import Sampler, apply_color_statistics
+    path = tmp_path / "unet_NV_best.pth"
+    torch.save(synthetic_sd, path)
+    s2 = Sampler(DEV)
+    s2.add_model("NV", torch.load(path, map_location="cpu"))               # model_manager.py:138-139
+    a, _ = sampler.generate(5, "NV", 4, count=2, size=(32, 32))
+    b, _ = s2.generate(5, "NV", 4, count=2, size=(32, 32))
+    assert np.array_equal(a, b)
+    stats = {"NV": {"rgb": {"mean": [190.0, 140.0, 120.0], "std": [35.0, 40.0, 45.0]}}}
+    s2.color_statistics = stats
+    c, _ = s2.generate(5, "NV", 4, count=2, size=(32, 32), postprocess=True)
+    assert np.array_equal(c, apply_color_statistics(a, stats["NV"])) and not np.array_equal(c, a)
+    d, _ = s2.generate(5, "NV", 4, count=2, size=(32, 32), postprocess=False)
+    assert np.array_equal(d, a)

@@ -194,3 +194,37 @@ def test_product_does_not_import_oracle():
             if fn.endswith(".py"):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{fn} imports the oracle"
+
+
+def test_color_postprocessing_matches_oracle_bit_exact(tmp_path):
+    """image_generator.py:502-545: the batched host function == the per-image restatement, including the clip of the
+    scale, an all-constant image (zero variance) and the no-op cases."""
+    import json
+    import numpy as np
+    from oracle import sampler as osampler
+    from synt_isic_amd import sampler
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, size=(5, 32, 24, 3), dtype=np.uint8)
+    imgs[3] = 77                                               # zero variance: scale clips at 1.4, mean moves
+    imgs[4, :, :, 0] = rng.integers(100, 104, size=(32, 24))   # tiny variance in one channel
+    stats = {"rgb": {"mean": [180.5, 120.25, 90.0], "std": [40.0, 55.5, 10.0]}}
+    got = sampler.apply_color_statistics(imgs, stats)
+    assert got.dtype == np.uint8 and got.shape == imgs.shape
+    for b in range(imgs.shape[0]):
+        assert np.array_equal(got[b], osampler.color_postprocess(imgs[b], stats))
+    assert not np.array_equal(got, imgs)
+    # documented no-ops: unknown class / entry without rgb.mean
+    assert sampler.apply_color_statistics(imgs, None) is imgs
+    assert sampler.apply_color_statistics(imgs, {"rgb": {"std": [1, 2, 3]}}) is imgs
+    # defaults when std is absent
+    only_mean = {"rgb": {"mean": [10, 20, 30]}}
+    assert np.array_equal(sampler.apply_color_statistics(imgs[:1], only_mean)[0], osampler.color_postprocess(imgs[0], only_mean))
+    # a known answer worked by hand: constant image 100, target mean 200 -> 0.35*(0*1.4+200) + 0.65*100 = 135
+    const = np.full((1, 4, 4, 3), 100, dtype=np.uint8)
+    assert np.all(sampler.apply_color_statistics(const, {"rgb": {"mean": [200, 200, 200], "std": [50, 50, 50]}}) == 135)
+    # the JSON loader (checkpoints/color_statistics.json); a missing file is not an error
+    s = sampler.Sampler.__new__(sampler.Sampler)
+    s.color_statistics = {}
+    assert s.load_color_statistics(str(tmp_path / "missing.json")) == 0
+    (tmp_path / "color_statistics.json").write_text(json.dumps({"NV": stats, "MEL": only_mean}))
+    assert s.load_color_statistics(str(tmp_path / "color_statistics.json")) == 2 and "NV" in s.color_statistics
