@@ -82,7 +82,10 @@ def test_timestep_argument_forms(model, synthetic_sd):
         model(torch.zeros(1, 4, 32, 32, device=DEV), 1)
 
 
-@pytest.mark.parametrize("B,H,W,t", [(1, 128, 128, 999), (1, 72, 40, 0), (3, 8, 8, 500), (1, 64, 64, 20)])
+@pytest.mark.parametrize("B,H,W,t", [(1, 128, 128, 999), (1, 72, 40, 0), (3, 8, 8, 500), (1, 64, 64, 20),
+                                     (6, 32, 32, 321),      # 8x8 level on the four-image K-split tiling, batch not a multiple of 4
+                                     (5, 40, 24, 77),       # ragged tiles at every level
+                                     (1, 256, 256, 7)])     # attention over 4096 and 1024 tokens
 def test_forward_other_resolutions(model, synthetic_sd, B, H, W, t):
     """fully convolutional: any H, W divisible by 8 (128x128 is the reference's native size)."""
     from oracle import unet as ounet
