@@ -75,7 +75,7 @@ class NoiseStream:
     """
 
     def __init__(self, seeds: Sequence[int], chw: Tuple[int, int, int], device: torch.device, segment_steps: int,
-                 workers: Optional[int] = None):
+                 workers: Optional[int] = None, buffer_cache: Optional[dict] = None):
         self.chw = tuple(chw)
         self.B = len(seeds)
         self.device = device
@@ -95,8 +95,17 @@ class NoiseStream:
         self.x_T = torch.empty((self.B,) + self.chw, dtype=torch.float32)
         list(self.pool.map(self._draw_x, range(self.B)))
         shape = (self.seg, self.B) + self.chw
-        self.host = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
-        self.dev = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
+        # pinning ~100 MB costs tens of milliseconds: a caller that samples repeatedly (Sampler) passes a dict in which
+        # the two pinned and two device buffers of a shape are kept between calls
+        key = (shape, str(device))
+        if buffer_cache is not None and key in buffer_cache:
+            self.host, self.dev = buffer_cache[key]
+        else:
+            self.host = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self.dev = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
+            if buffer_cache is not None:
+                buffer_cache.clear()                    # one shape at a time: bounded memory
+                buffer_cache[key] = (self.host, self.dev)
         self.copy_stream = torch.cuda.Stream(device)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]      # upload of slot i finished
         self.uploaded = [False, False]
@@ -274,6 +283,7 @@ class Sampler:
         self.cancel = C.c_int(0)          # cooperative stop flag (image_generator.py:320,396)
         self.noise_segment_steps = 64     # steps of noise drawn and uploaded per pipeline stage (NoiseStream)
         self.color_statistics: Dict[str, dict] = {}   # class -> color_statistics.json entry (image_generator.py:142-170)
+        self._noise_buffers: dict = {}    # pinned/device staging buffers of the last noise shape (NoiseStream)
 
     def load_color_statistics(self, path: str) -> int:
         """``checkpoints/color_statistics.json`` (image_generator.py:142-170); returns the number of classes read.
@@ -313,7 +323,8 @@ class Sampler:
         H, W = size
         # noise is drawn segment by segment on worker threads while the GPU samples (NoiseStream); the values are
         # those of draw_noise(seeds, n_noise, ...)
-        ns = NoiseStream(seeds, (model.config.in_channels, H, W), self.device, self.noise_segment_steps)
+        ns = NoiseStream(seeds, (model.config.in_channels, H, W), self.device, self.noise_segment_steps,
+                         buffer_cache=self._noise_buffers)
         try:
             hashes = [noise_hash(ns.x_T[b:b + 1]) for b in range(len(seeds))]
             res = run_sampling_loop(model, sched, ns.x_T.to(self.device), ns if n_noise else None,
