@@ -580,7 +580,8 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     SISIC_REQUIRE((cfg < 60 || cfg > 71) && cfg != 90, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
-        if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 4>(ctx, p, s);
+        if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 2>(ctx, p, s);   // 2-channel chunks: 4 spill 256 B/lane (13 weight float4 + 15 halo elements per thread)
+        if (cfg == 42) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 4>(ctx, p, s);
     } else if (a.ksize == 1 && a.stride == 2) {
         if (cfg == 0) cfg = p.Wout >= 24 ? 31 : (p.Wout >= 12 ? 32 : 33);
         switch (cfg) {
