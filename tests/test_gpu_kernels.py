@@ -549,3 +549,67 @@ def test_denorm_u8_bit_exact():
     got = ops.denorm_u8(x.to(DEV)).cpu().numpy()
     assert got.shape == (3, 20, 12, 3) and got.dtype == np.uint8
     assert np.array_equal(got, osampler.denormalize_to_uint8(x))
+
+
+def test_conv2d_auto_dispatch_fuzz():
+    """sisic_conv2d with tile_cfg = 0 over 80 seeded random shapes and feature combinations against the float64
+    convolution: whatever kernel the dispatch picks (direct, flat 1x1 with float4 staging, Winograd, nine-position
+    upsample form, K-split form, vector-ALU small-Cout) must agree, and the GroupNorm partials it reports must
+    reproduce the statistics of what it stored."""
+    import random
+    from synt_isic_amd import ops
+    rnd = random.Random(20261004)
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    picked = set()
+    for case in range(80):
+        k = rnd.choice([1, 3, 3, 3])
+        stride = rnd.choice([1, 1, 1, 2])
+        ups = k == 3 and stride == 1 and rnd.random() < 0.2
+        B = rnd.choice([1, 2, 3, 5, 8])
+        H, W = rnd.choice([4, 6, 8, 8, 9, 12, 16, 16, 20, 32, 40]), rnd.choice([4, 5, 8, 8, 10, 16, 16, 24, 32, 36])
+        if ups:
+            H, W = min(H, 16), min(W, 16)
+        c0 = rnd.choice([3, 8, 20, 64, 128, 256])
+        c1 = rnd.choice([0, 0, 12, 64, 128])
+        cout = rnd.choice([3, 4, 32, 64, 70, 128, 256])
+        if c0 + c1 > 256 and H * W > 400:
+            H, W = 16, 16
+        Cin = c0 + c1
+        x = _rand(B, c0, H, W, seed=1000 + case)
+        x2 = _rand(B, c1, H, W, seed=2000 + case) if c1 else None
+        w = _rand(cout, Cin, k, k, seed=3000 + case, scale=(Cin * k * k) ** -0.5)
+        kw = {"stride": stride, "upsample": ups, "x2": x2}
+        if rnd.random() < 0.7:
+            kw["bias"] = _rand(cout, seed=4000 + case)
+        if rnd.random() < 0.5:
+            kw["gn"] = (1.0 + 0.3 * _rand(B, Cin, seed=5000 + case), 0.3 * _rand(B, Cin, seed=6000 + case))
+            kw["gn_silu"] = rnd.random() < 0.7
+        if rnd.random() < 0.4:
+            kw["chan_bias"] = _rand(B, cout, seed=7000 + case)
+        Hc, Wc = (2 * H, 2 * W) if ups else (H, W)
+        Ho, Wo = (Hc + 2 * (k // 2) - k) // stride + 1, (Wc + 2 * (k // 2) - k) // stride + 1
+        if rnd.random() < 0.5:
+            kw["residual"] = _rand(B, cout, Ho, Wo, seed=8000 + case)
+        kw["relu"] = rnd.random() < 0.2
+        ref = _conv_ref(x, w, kw.get("bias"), x2=x2, stride=stride, upsample=ups, gn=kw.get("gn"),
+                        gn_silu=kw.get("gn_silu", False), chan_bias=kw.get("chan_bias"), residual=kw.get("residual"),
+                        relu=kw["relu"])
+        gn = kw.get("gn")
+        wino = ops.pack_winograd_weight(d(w)) if (k == 3 and rnd.random() < 0.8) else None
+        y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, k, bias=d(kw.get("bias")), x2=d(x2), stride=stride,
+                           upsample=ups, gn_scale=d(gn[0]) if gn else None, gn_shift=d(gn[1]) if gn else None,
+                           gn_silu=kw.get("gn_silu", False), chan_bias=d(kw.get("chan_bias")),
+                           residual=d(kw.get("residual")), relu=kw["relu"], w_winograd=wino, with_stats=True)
+        what = f"case {case}: k{k} s{stride} ups{int(ups)} B{B} {c0}+{c1}->{cout} @{H}x{W} wino={wino is not None}"
+        _close(y, ref, tol=3e-5, what=what)
+        picked.add((k, stride, ups, wino is not None, st is not None))
+        if st is not None:
+            stc, yc = st.cpu().double(), y.cpu().double()
+            n = stc[..., 0].sum(-1)
+            assert torch.equal(n, torch.full_like(n, float(Ho * Wo))), what
+            mean = stc[..., 1].sum(-1) / n
+            _close(mean.float(), yc.mean((2, 3)), tol=1e-5, what=what + " (partial sums)")
+            mean_i = stc[..., 1] / stc[..., 0].clamp(min=1)
+            m2 = stc[..., 2].sum(-1) + (stc[..., 0] * (mean_i - mean[..., None]) ** 2).sum(-1)
+            _close((m2 / n).float(), yc.var((2, 3), unbiased=False), tol=1e-4, what=what + " (partial M2)")
+    assert len(picked) >= 8          # the draw really covered the dispatch space
