@@ -65,7 +65,9 @@ typedef struct sisic_conv_args {
     const float* in1;       /* dev [B,c1,Hin,Win] or NULL                */
     int c0, c1;
     int B, Hin, Win;
-    int upsample;           /* 1: nearest 2x before the conv              */
+    int upsample;           /* 1: nearest 2x before the conv; 2: zero insertion (source at the even
+                               coordinates of the 2x grid, zeros elsewhere) = the input side of a
+                               transposed stride-2 convolution (classifier backward-to-input)        */
     int ksize;              /* 1, 3 or 7                                  */
     int stride;             /* 1 or 2                                     */
     const float* w_packed;  /* dev, layout of sisic_conv_pack_weights     */
@@ -203,6 +205,13 @@ int sisic_resnet_load(sisic_resnet*, int n, const char* const* names, const floa
  * normalised network input [B,3,H,W].                                                         */
 int sisic_resnet_forward(sisic_resnet*, const float* x, float* logits, int B, int H, int W, int preprocess,
                          void* stream);
+/* d score / d x of the classifier for score = log(softmax(logits)[target] + 1e-8) (xai/XAI.py:443-459), x = the raw
+ * input in [-1,1] with the pre-processing differentiated through (clamp, bilinear 224x224, normalise): the gradient
+ * captum's IntegratedGradients(forward_func = get_per_class_score) and the plain-gradient fallback of
+ * xai/XAI.py:1039-1109 take.  grad_x: dev [B,3,H,W]; logits_out: dev [B,n_classes] or NULL.              */
+int sisic_resnet_input_gradient(sisic_resnet*, const float* x, int B, int H, int W, int target,
+                                float* grad_x, float* logits_out, void* stream);
+
 /* get_confidence / get_per_class_score (XAI.py:443-471): prob[b] = softmax(logits[b])[target],
  * logscore[b] = log(prob[b] + 1e-8); either output may be NULL.                               */
 int sisic_class_scores(sisic_ctx*, const float* logits, int B, int n_classes, int target, float* prob,

@@ -111,6 +111,28 @@ def class_scores(sd, x: torch.Tensor, target_class: int):
     return p, torch.log(p + 1e-8)
 
 
+def score_input_gradient(sd, x: torch.Tensor, target_class: int):
+    """d/dx of get_per_class_score = log(softmax(forward(x))[:, c] + 1e-8) by autograd over the restatement above
+    (what ``_compute_gradient_attribution``, XAI.py:1086-1109, returns per sample, and what captum's
+    IntegratedGradients differentiates at every Riemann point).  Returns (grad [B,3,H,W], logits [B,n])."""
+    with torch.enable_grad():
+        xg = x.detach().clone().requires_grad_(True)
+        logits = resnet18_features(sd, preprocess_for_classifier(xg))
+        score = torch.log(F.softmax(logits, dim=1)[:, target_class] + 1e-8)
+        (grad,) = torch.autograd.grad(score.sum(), xg)
+    return grad.detach(), logits.detach()
+
+
+def integrated_gradients(sd, image: torch.Tensor, target_class: int, baseline: torch.Tensor, n_steps: int = 50):
+    """captum IntegratedGradients.attribute(image, baselines=baseline, n_steps, method='riemann_right') for the
+    per-class score (XAI.py:1039-1084): (x - x') * mean_k grad(x' + k/n (x - x')), k = 1..n."""
+    total = torch.zeros_like(image)
+    for k in range(1, n_steps + 1):
+        point = baseline + (k / n_steps) * (image - baseline)
+        total += score_input_gradient(sd, point, target_class)[0]
+    return (image - baseline) * total / n_steps
+
+
 def expand_patch_mask(patch_mask: torch.Tensor, H: int, W: int, patch: int) -> torch.Tensor:
     """XAI.py:1149-1157: boolean patch grid -> boolean pixel mask (pixels beyond the grid stay False)."""
     full = torch.zeros(H, W, dtype=torch.bool)

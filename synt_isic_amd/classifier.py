@@ -189,5 +189,23 @@ class HipMelanomaClassifier:
         """p(c|x)   (XAI.py:467-471)."""
         return self._scores(x, target_class)[0]
 
+    def input_gradient(self, x: torch.Tensor, target_class: int):
+        """(d get_per_class_score / d x, logits): the gradient captum's IntegratedGradients and the plain-gradient
+        fallback of XAI.py:1039-1109 take, through the pre-processing, with no autograd graph -- the transposed
+        network runs on the same HIP convolution kernels (sisic_resnet_input_gradient)."""
+        h = self.handle
+        if x.device != self._device:
+            x = x.to(self._device)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"classifier input must be [B,3,H,W], got {tuple(x.shape)}")
+        x = x.detach().to(torch.float32).contiguous()
+        B, _, H, W = x.shape
+        grad = torch.empty_like(x)
+        logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=x.device)
+        check(_lib.load().sisic_resnet_input_gradient(h, x.data_ptr(), B, H, W, int(target_class), grad.data_ptr(),
+                                                      logits.data_ptr(),
+                                                      C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return grad, logits
+
     def predict(self, x: torch.Tensor) -> torch.Tensor:
         return torch.argmax(self.forward(x), dim=1)

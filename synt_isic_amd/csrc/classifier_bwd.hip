@@ -1,0 +1,266 @@
+// classifier_bwd.hip -- gradient of the per-class score with respect to the classifier INPUT (SURVEY.md section 8f
+// rank 3): what captum's IntegratedGradients and the plain-gradient fallback of xai/XAI.py:1039-1109 differentiate,
+//     score(x) = log(softmax(resnet18(preprocess(x)))[c] + 1e-8)          (XAI.py:443-459)
+// The convolutions of the backward pass are convolutions too and run on the forward kernels (conv_mfma.hip /
+// conv_winograd.hip) with transposed, tap-flipped filters -- stride 2 through the zero-insertion input mode --
+// so this file only holds what is not a convolution:
+//   * score_head_bwd_kernel : d score / d (last activation): softmax/log, Linear, global average pool, ReLU mask
+//   * relu_bwd_kernel       : dy * [y > 0]
+//   * scatter_add_even      : the input side of a transposed 1x1 stride-2 convolution (downsample branch)
+//   * maxpool_bwd_kernel    : MaxPool2d(3, 2, 1) backward with PyTorch's first-maximum tie rule, fused ReLU mask
+//   * stem_bwd_kernel       : transposed 7x7 stride-2 convolution of the stem (64 -> 3 channels at 224x224)
+//   * preprocess_bwd_kernel : adjoint of normalise . bilinear(align_corners=False) . clamp((x+1)/2, 0, 1)
+#include "common.h"
+
+namespace sisic {
+
+// g[b,c,p] = [act > 0] * (1/HW) * sum_k W[k,c] * dscore/dlogit_k,   dscore/dlogit_k = p_t/(p_t + 1e-8) * (delta_kt - p_k)
+__global__ void __launch_bounds__(256)
+score_head_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ fc_w, const float* __restrict__ act,
+                      float* __restrict__ g, int C, int HW, int n_classes, int target, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        const int64_t b = i / ((int64_t)HW * C);
+        const float* lg = logits + b * n_classes;
+        float m = lg[0];
+        for (int k = 1; k < n_classes; ++k) m = fmaxf(m, lg[k]);
+        float sum = 0.0f;
+        for (int k = 0; k < n_classes; ++k) sum += expf(lg[k] - m);
+        const float pt = expf(lg[target] - m) / sum;
+        const float coef = pt / (pt + 1e-8f);
+        float d = 0.0f;
+        for (int k = 0; k < n_classes; ++k) {
+            const float pk = expf(lg[k] - m) / sum;
+            d += fc_w[(size_t)k * C + c] * (coef * ((k == target ? 1.0f : 0.0f) - pk));
+        }
+        g[i] = act[i] > 0.0f ? d / (float)HW : 0.0f;
+    }
+}
+
+int launch_score_head_bwd(sisic_ctx* ctx, const float* logits, const float* fc_w, const float* act, float* g, int B, int C,
+                          int HW, int n_classes, int target, hipStream_t s) {
+    SISIC_REQUIRE(logits && fc_w && act && g && target >= 0 && target < n_classes, "score_head_bwd: bad arguments");
+    const int64_t total = (int64_t)B * C * HW;
+    ProfileScope prof(ctx, s, PK_OTHER, 8.0 * total, 0.0);
+    hipLaunchKernelGGL(score_head_bwd_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s,
+                       logits, fc_w, act, g, C, HW, n_classes, target, total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+__global__ void __launch_bounds__(256)
+relu_bwd_kernel(const float* dy, const float* y, float* out, int64_t n) {     // out may alias dy
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+int launch_relu_bwd(sisic_ctx* ctx, const float* dy, const float* y, float* out, int64_t n, hipStream_t s) {
+    SISIC_REQUIRE(dy && y && out && n > 0, "relu_bwd: bad arguments");
+    ProfileScope prof(ctx, s, PK_OTHER, 12.0 * n, 0.0);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, s, dy, y, out, n);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// dst[b,c,2i,2j] += src[b,c,i,j]   (dst is [planes,H,W], src [planes,OH,OW] with OH = (H-1)/2+1)
+__global__ void __launch_bounds__(256)
+scatter_add_even_kernel(float* __restrict__ dst, const float* __restrict__ src, int H, int W, int OH, int OW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % OW);
+        const int64_t r = i / OW;
+        const int ii = (int)(r % OH);
+        const int64_t plane = r / OH;
+        dst[(plane * H + 2 * ii) * W + 2 * j] += src[i];
+    }
+}
+
+int launch_scatter_add_even(sisic_ctx* ctx, float* dst, const float* src, int planes, int H, int W, hipStream_t s) {
+    SISIC_REQUIRE(dst && src && planes > 0 && H > 0 && W > 0, "scatter_add_even: bad arguments");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int64_t total = (int64_t)planes * OH * OW;
+    ProfileScope prof(ctx, s, PK_OTHER, 12.0 * total, 0.0);
+    hipLaunchKernelGGL(scatter_add_even_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 16384)), dim3(256), 0, s,
+                       dst, src, H, W, OH, OW, total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// MaxPool2d(3, 2, 1) backward in gather form, then the ReLU mask of the pooled tensor's producer:
+//   dx[y,x] = [x_in[y,x] > 0] * sum over the (up to four) windows that contain (y,x) and whose FIRST maximum in
+//   row-major scan order is at (y,x) of dm[window]         (PyTorch's max_pool2d tie rule)
+__global__ void __launch_bounds__(256)
+maxpool_bwd_kernel(const float* __restrict__ dm, const float* __restrict__ xin, float* __restrict__ dx, int H, int W,
+                   int OH, int OW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int64_t r = i / W;
+        const int y = (int)(r % H);
+        const int64_t plane = r / H;
+        const float* src = xin + plane * (int64_t)H * W;
+        const float v = src[(int64_t)y * W + x];
+        float acc = 0.0f;
+        if (v > 0.0f) {
+            // windows (oy, ox) with 2*oy - 1 <= y <= 2*oy + 1
+            for (int oy = (y + 1) / 2 - ((y + 1) % 2 == 0 ? 1 : 0); oy <= (y + 1) / 2; ++oy) {
+                if (oy < 0 || oy >= OH) continue;
+                for (int ox = (x + 1) / 2 - ((x + 1) % 2 == 0 ? 1 : 0); ox <= (x + 1) / 2; ++ox) {
+                    if (ox < 0 || ox >= OW) continue;
+                    // first maximum of the window in scan order
+                    float best = -INFINITY;
+                    int by = -1, bx = -1;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int yy = 2 * oy - 1 + ky;
+                        if (yy < 0 || yy >= H) continue;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int xx = 2 * ox - 1 + kx;
+                            if (xx < 0 || xx >= W) continue;
+                            const float t = src[(int64_t)yy * W + xx];
+                            if (t > best) { best = t; by = yy; bx = xx; }
+                        }
+                    }
+                    if (by == y && bx == x) acc += dm[(plane * OH + oy) * (int64_t)OW + ox];
+                }
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+int launch_maxpool_bwd(sisic_ctx* ctx, const float* dm, const float* xin, float* dx, int planes, int H, int W, hipStream_t s) {
+    SISIC_REQUIRE(dm && xin && dx && planes > 0, "maxpool_bwd: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)planes * H * W;
+    ProfileScope prof(ctx, s, PK_OTHER, 8.0 * total, 0.0);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 32768)), dim3(256), 0, s, dm,
+                       xin, dx, H, W, OH, OW, total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// Transposed 7x7 stride-2 padding-3 convolution, 64 -> 3 channels:
+//   dp[b,ci,Y,X] = sum_{co,ky,kx} W[co,ci,ky,kx] * g[b,co,(Y+3-ky)/2,(X+3-kx)/2]   over the taps for which both
+//   quotients are integers inside the map.  W = the BN-folded OIHW stem filter.  One thread per (b, Y, X); the
+//   filter sits in LDS as [co][ky][kx][ci(4)] so that the three input channels of a tap are one ds_read_b128.
+__global__ void __launch_bounds__(256)
+stem_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dp, int CO, int OH, int OW,
+                int H, int W, int64_t total) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [CO][49][4]
+    for (int i = threadIdx.x; i < CO * 49; i += blockDim.x) {
+        const int co = i / 49, tap = i % 49;
+        wl[i * 4 + 0] = w[((size_t)co * 3 + 0) * 49 + tap];
+        wl[i * 4 + 1] = w[((size_t)co * 3 + 1) * 49 + tap];
+        wl[i * 4 + 2] = w[((size_t)co * 3 + 2) * 49 + tap];
+        wl[i * 4 + 3] = 0.0f;
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W);
+        const int64_t r = i / W;
+        const int Y = (int)(r % H);
+        const int64_t b = r / H;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        const int ky0 = (Y + 3) & 1, kx0 = (X + 3) & 1;              // taps with the right parity
+        for (int co = 0; co < CO; ++co) {
+            const float* gp = g + ((size_t)b * CO + co) * OH * OW;
+            for (int ky = ky0; ky < 7; ky += 2) {
+                const int oy = (Y + 3 - ky) >> 1;
+                if (oy < 0 || oy >= OH) continue;
+                for (int kx = kx0; kx < 7; kx += 2) {
+                    const int ox = (X + 3 - kx) >> 1;
+                    if (ox < 0 || ox >= OW) continue;
+                    const float gv = gp[(size_t)oy * OW + ox];
+                    const float4 wv = *reinterpret_cast<const float4*>(&wl[((co * 7 + ky) * 7 + kx) * 4]);
+                    a0 += gv * wv.x;
+                    a1 += gv * wv.y;
+                    a2 += gv * wv.z;
+                }
+            }
+        }
+        const size_t HWp = (size_t)H * W;
+        float* o = dp + (size_t)b * 3 * HWp + (size_t)Y * W + X;
+        o[0] = a0;
+        o[HWp] = a1;
+        o[2 * HWp] = a2;
+    }
+}
+
+int launch_stem_bwd(sisic_ctx* ctx, const float* g, const float* w_oihw, float* dp, int B, int CO, int OH, int OW, int H,
+                    int W, hipStream_t s) {
+    SISIC_REQUIRE(g && w_oihw && dp && B > 0 && CO > 0 && CO * 49 * 16 <= 160 * 1024, "stem_bwd: bad arguments");
+    SISIC_REQUIRE(OH == (H + 6 - 7) / 2 + 1 && OW == (W + 6 - 7) / 2 + 1, "stem_bwd: %dx%d is not the stem output of %dx%d", OH, OW, H, W);
+    const int64_t total = (int64_t)B * H * W;
+    const size_t lds = (size_t)CO * 49 * 4 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    ProfileScope prof(ctx, s, PK_OTHER, 4.0 * B * ((double)CO * OH * OW + 3.0 * H * W), 2.0 * B * 3.0 * CO * 49.0 * OH * OW);
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), lds, s, g, w_oihw,
+                       dp, CO, OH, OW, H, W, total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// Adjoint of preprocess_kernel (classifier.hip):  p = (bilinear(clamp((x+1)/2, 0, 1)) - mean) / std.
+//   dx[b,c,y,x] = 0.5 * [0 <= (x+1)/2 <= 1] / std_c * sum_{Y,X} wy(Y,y) * wx(X,x) * dp[b,c,Y,X]
+// with the forward's own source-index arithmetic recomputed per target row/column, so every edge case (clamped source
+// coordinate at the top/left, duplicated last row/column) is the forward's by construction.
+__global__ void __launch_bounds__(256)
+preprocess_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ x, float* __restrict__ dx, int C, int H, int W,
+                      int OH, int OW, float sh, float sw, float is0, float is1, float is2, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xs = (int)(i % W);
+        int64_t r = i / W;
+        const int ys = (int)(r % H);
+        r /= H;
+        const int c = (int)(r % C);
+        const int64_t b = r / C;
+        const float u = (x[i] + 1.0f) / 2.0f;
+        float acc = 0.0f;
+        if (u >= 0.0f && u <= 1.0f) {
+            const float* src = dp + (b * C + c) * (int64_t)OH * OW;
+            if (OH == H && OW == W) {
+                acc = src[(int64_t)ys * W + xs];
+            } else {
+                // target rows whose two source rows can include ys: source coordinate in (ys - 1, ys + 1)
+                const int Ylo = max(0, (int)floorf(((float)ys - 0.5f) / sh - 0.5f) - 1);
+                const int Yhi = min(OH - 1, (int)ceilf(((float)ys + 1.5f) / sh - 0.5f) + 1);
+                const int Xlo = max(0, (int)floorf(((float)xs - 0.5f) / sw - 0.5f) - 1);
+                const int Xhi = min(OW - 1, (int)ceilf(((float)xs + 1.5f) / sw - 0.5f) + 1);
+                for (int Y = Ylo; Y <= Yhi; ++Y) {
+                    const float fy = fmaxf(sh * ((float)Y + 0.5f) - 0.5f, 0.0f);
+                    const int y0 = min((int)fy, H - 1), y1 = min(y0 + 1, H - 1);
+                    const float ly = fy - (float)y0;
+                    const float wy = (y0 == ys ? 1.0f - ly : 0.0f) + (y1 == ys ? ly : 0.0f);
+                    if (wy == 0.0f) continue;
+                    float row = 0.0f;
+                    for (int X = Xlo; X <= Xhi; ++X) {
+                        const float fx = fmaxf(sw * ((float)X + 0.5f) - 0.5f, 0.0f);
+                        const int x0 = min((int)fx, W - 1), x1 = min(x0 + 1, W - 1);
+                        const float lx = fx - (float)x0;
+                        const float wx = (x0 == xs ? 1.0f - lx : 0.0f) + (x1 == xs ? lx : 0.0f);
+                        if (wx != 0.0f) row += wx * src[(int64_t)Y * OW + X];
+                    }
+                    acc += wy * row;
+                }
+            }
+            acc *= 0.5f * (c == 0 ? is0 : (c == 1 ? is1 : is2));
+        }
+        dx[i] = acc;
+    }
+}
+
+int launch_preprocess_bwd(sisic_ctx* ctx, const float* dp, const float* x, float* dx, int B, int H, int W, int OH, int OW,
+                          hipStream_t s) {
+    SISIC_REQUIRE(dp && x && dx && B > 0 && H <= OH && W <= OW, "preprocess_bwd: bad arguments");
+    const int64_t total = (int64_t)B * 3 * H * W;
+    ProfileScope prof(ctx, s, PK_OTHER, 4.0 * B * 3 * ((double)2 * H * W + (double)OH * OW), 0.0);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, dp, x,
+                       dx, 3, H, W, OH, OW, (float)H / (float)OH, (float)W / (float)OW, 1.0f / 0.229f, 1.0f / 0.224f,
+                       1.0f / 0.225f, total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+}  // namespace sisic

@@ -97,6 +97,15 @@ inline int conv_cout_pad(int cout) { return round_up(cout, CONV_CO_TILE); }
 int launch_conv2d(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
 int launch_conv_smallcout(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
 // conv_winograd.hip: F(2x2,3x3) for 3x3 stride-1 convolutions
+int launch_score_head_bwd(sisic_ctx*, const float* logits, const float* fc_w, const float* act, float* g, int B, int C,
+                          int HW, int n_classes, int target, hipStream_t s);
+int launch_relu_bwd(sisic_ctx*, const float* dy, const float* y, float* out, int64_t n, hipStream_t s);
+int launch_scatter_add_even(sisic_ctx*, float* dst, const float* src, int planes, int H, int W, hipStream_t s);
+int launch_maxpool_bwd(sisic_ctx*, const float* dm, const float* xin, float* dx, int planes, int H, int W, hipStream_t s);
+int launch_stem_bwd(sisic_ctx*, const float* g, const float* w_oihw, float* dp, int B, int CO, int OH, int OW, int H, int W,
+                    hipStream_t s);
+int launch_preprocess_bwd(sisic_ctx*, const float* dp, const float* x, float* dx, int B, int H, int W, int OH, int OW,
+                          hipStream_t s);
 int conv_stats_slots(const sisic_conv_args& a);
 int launch_gn_finalize(sisic_ctx*, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
                        int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,

@@ -36,6 +36,7 @@ struct ConvParams {
     int Hc, Wc;        // conv input extent (after the optional 2x upsample)
     int Hout, Wout;
     int ups;
+    int zero_insert;   // with ups: the 2x grid holds the source at even coordinates and zeros elsewhere (transposed stride-2 conv)
     const float* w;    // packed [Cin_pad][KK][cout_pad]
     int cout_pad;
     const float* bias;
@@ -152,7 +153,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
         const int yy = e / G::IW, xx = e % G::IW;
         const int gy = oy0 * STRIDE - G::PAD + yy;
         const int gx = ox0 * STRIDE - G::PAD + xx;
-        const bool v = (e < G::IH * G::IW) && gy >= 0 && gy < p.Hc && gx >= 0 && gx < p.Wc;
+        const bool v = (e < G::IH * G::IW) && gy >= 0 && gy < p.Hc && gx >= 0 && gx < p.Wc &&
+                       !(p.zero_insert && ((gy | gx) & 1));
         goff[i] = v ? ((gy >> p.ups) * p.Win + (gx >> p.ups)) : 0;
         vmask |= (v ? 1u : 0u) << i;
     }
@@ -488,7 +490,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
 // tile_cfg 60..71 / 90, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
 // there are 32-bit).  Returns the tile configuration, 0 = not Winograd.
 static int winograd_cfg(const sisic_conv_args& a) {
-    if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4)) return 0;
+    if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4) || a.upsample == 2) return 0;
     if ((a.tile_cfg >= 60 && a.tile_cfg <= 71) || a.tile_cfg == 90) return a.tile_cfg;
     if (a.tile_cfg != 0) return 0;
     const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
@@ -540,6 +542,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1;
     p.B = a.B; p.Hin = a.Hin; p.Win = a.Win;
     p.ups = a.upsample ? 1 : 0;
+    p.zero_insert = a.upsample == 2 ? 1 : 0;
     p.Hc = a.Hin << p.ups; p.Wc = a.Win << p.ups;
     const int pad = a.ksize / 2;
     p.Hout = (p.Hc + 2 * pad - a.ksize) / a.stride + 1;

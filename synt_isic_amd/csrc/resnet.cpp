@@ -23,6 +23,10 @@ struct FoldedConv {
     float* packed = nullptr;
     float* wino = nullptr;           // Winograd-domain filters of the BN-folded weight (3x3 stride 1 only)
     float* bias = nullptr;
+    // backward-to-input (sisic_resnet_input_gradient): the same convolution with transposed, tap-flipped filters
+    float* raw = nullptr;            // BN-folded OIHW weight on the device (the stem's transposed convolution reads it)
+    float* packed_t = nullptr;       // packed [cout -> cin] filters W'[ci][co][a][b] = W[co][ci][k-1-a][k-1-b]
+    float* wino_t = nullptr;         // their Winograd form (3x3 stride 1 only)
 };
 
 struct Block {
@@ -130,6 +134,24 @@ int fold(sisic_resnet* r, FoldedConv& c) {
     }
     SISIC_TRY(dev_alloc(r, c.cout, &c.bias));
     SISIC_HIP(hipMemcpy(c.bias, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+    c.raw = raw;
+    if (c.k != 7) {                      // backward filters (the 7x7 stem has its own kernel, classifier_bwd.hip)
+        const int kk = c.k * c.k;
+        std::vector<float> wt(wf.size());
+        for (int co = 0; co < c.cout; ++co)
+            for (int ci = 0; ci < c.cin; ++ci)
+                for (int t = 0; t < kk; ++t)
+                    wt[((size_t)ci * c.cout + co) * kk + (kk - 1 - t)] = wf[((size_t)co * c.cin + ci) * kk + t];
+        float* rawt = nullptr;
+        SISIC_TRY(dev_alloc(r, wt.size(), &rawt));
+        SISIC_HIP(hipMemcpy(rawt, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        SISIC_TRY(dev_alloc(r, (size_t)sisic_conv_packed_numel(c.cin, c.cout, c.k), &c.packed_t));
+        SISIC_TRY(launch_conv_pack(r->ctx, rawt, c.cin, c.cout, c.k, c.packed_t, nullptr));
+        if (c.k == 3 && c.stride == 1) {
+            SISIC_TRY(dev_alloc(r, (size_t)winograd_packed_numel(c.cin, c.cout), &c.wino_t));
+            SISIC_TRY(launch_winograd_pack(r->ctx, rawt, c.cin, c.cout, c.wino_t, nullptr));
+        }
+    }
     return SISIC_OK;
 }
 
@@ -294,6 +316,143 @@ int sisic_resnet_forward(sisic_resnet* r, const float* x, float* logits, int B, 
         }
         SISIC_TRY(launch_avgpool_fc(r->ctx, act, r->d_fc_w, r->d_fc_b, logits, B, ch, h * w, r->num_classes, s));
         put(act);
+        return SISIC_OK;
+    };
+    const int rc = body();
+    for (float* p : live) pool_put(r, p);
+    return rc;
+}
+
+// d score / d x for score = log(softmax(logits)[target] + 1e-8) (XAI.py:443-459), x the classifier's raw input in
+// [-1,1] (pre-processing included): the quantity captum's IntegratedGradients and the plain-gradient fallback of
+// XAI.py:1039-1109 differentiate.  Forward with the activations kept, then the transposed network (see
+// classifier_bwd.hip); every convolution of the backward pass is a sisic_conv2d launch with transposed filters.
+int sisic_resnet_input_gradient(sisic_resnet* r, const float* x, int B, int H, int W, int target, float* grad_x,
+                                float* logits_out, void* stream) {
+    SISIC_REQUIRE(r && x && grad_x && B > 0 && H > 0 && W > 0, "resnet_input_gradient: bad arguments");
+    SISIC_REQUIRE(target >= 0 && target < r->num_classes, "resnet_input_gradient: class %d of %d", target, r->num_classes);
+    if (!r->loaded) {
+        set_error("resnet_input_gradient called before sisic_resnet_load");
+        return SISIC_ESTATE;
+    }
+    SISIC_HIP(hipSetDevice(r->ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<float*> live;
+    auto get = [&](size_t floats, float** p) {
+        const int rc = pool_get(r, floats, p);
+        if (rc == SISIC_OK) live.push_back(*p);
+        return rc;
+    };
+    auto put = [&](float* p) {
+        pool_put(r, p);
+        live.erase(std::remove(live.begin(), live.end(), p), live.end());
+    };
+    // transposed convolution of `c` applied to g [B, c.cout, gh, gw]; stride 2: zero-insertion input (2gh x 2gw grid)
+    auto conv_t = [&](const FoldedConv& c, const float* g, int gh, int gw, const float* residual, float* out) {
+        sisic_conv_args a{};
+        a.in0 = g; a.c0 = c.cout; a.B = B; a.Hin = gh; a.Win = gw;
+        a.ksize = c.k; a.stride = 1;
+        a.upsample = (c.k == 3 && c.stride == 2) ? 2 : 0;
+        a.w_packed = c.packed_t; a.w_winograd = c.wino_t; a.Cout = c.cin;
+        a.residual = residual; a.out = out;
+        return launch_conv2d(r->ctx, a, s);
+    };
+    struct Saved { float* t1; float* out; int h, w, bh, bw; };
+    auto body = [&]() -> int {
+        const int S = 224;
+        SISIC_REQUIRE(H <= S && W <= S, "resnet_input_gradient: input %dx%d larger than the classifier's %dx%d", H, W, S, S);
+        float* pre = nullptr;
+        SISIC_TRY(get((size_t)B * 3 * S * S, &pre));
+        SISIC_TRY(launch_preprocess(r->ctx, x, pre, B, H, W, S, S, s));
+        int h = S, w = S;
+        const int c1h = out_dim(h, 7, 2), c1w = out_dim(w, 7, 2);
+        float* c1 = nullptr;
+        SISIC_TRY(get((size_t)B * 64 * c1h * c1w, &c1));
+        SISIC_TRY(run_conv(r, r->stem, pre, B, h, w, nullptr, true, c1, s));
+        put(pre);
+        const int mh = out_dim(c1h, 3, 2), mw = out_dim(c1w, 3, 2);
+        SISIC_REQUIRE(c1h % 2 == 0 && c1w % 2 == 0, "resnet_input_gradient: odd feature map");
+        float* m = nullptr;
+        SISIC_TRY(get((size_t)B * 64 * mh * mw, &m));
+        SISIC_TRY(launch_maxpool(r->ctx, c1, m, B, 64, c1h, c1w, s));
+        std::vector<Saved> saved;
+        float* act = m;
+        h = mh; w = mw;
+        for (const Block& b : r->blocks) {
+            const int bh = out_dim(h, 3, b.conv1.stride), bw = out_dim(w, 3, b.conv1.stride);
+            SISIC_REQUIRE(b.conv1.stride == 1 || (h % 2 == 0 && w % 2 == 0), "resnet_input_gradient: odd feature map %dx%d", h, w);
+            float* t1 = nullptr;
+            SISIC_TRY(get((size_t)B * b.conv1.cout * bh * bw, &t1));
+            SISIC_TRY(run_conv(r, b.conv1, act, B, h, w, nullptr, true, t1, s));
+            const float* identity = act;
+            float* ds = nullptr;
+            if (b.down.k) {
+                SISIC_TRY(get((size_t)B * b.down.cout * bh * bw, &ds));
+                SISIC_TRY(run_conv(r, b.down, act, B, h, w, nullptr, false, ds, s));
+                identity = ds;
+            }
+            float* t2 = nullptr;
+            SISIC_TRY(get((size_t)B * b.conv2.cout * bh * bw, &t2));
+            SISIC_TRY(run_conv(r, b.conv2, t1, B, bh, bw, identity, true, t2, s));
+            if (ds) put(ds);
+            saved.push_back({t1, t2, h, w, bh, bw});
+            act = t2; h = bh; w = bw;
+        }
+        const int C = r->blocks.back().conv2.cout;
+        float* logits = nullptr;
+        SISIC_TRY(get((size_t)B * r->num_classes, &logits));
+        SISIC_TRY(launch_avgpool_fc(r->ctx, act, r->d_fc_w, r->d_fc_b, logits, B, C, h * w, r->num_classes, s));
+        if (logits_out)
+            SISIC_HIP(hipMemcpyAsync(logits_out, logits, (size_t)B * r->num_classes * sizeof(float), hipMemcpyDeviceToDevice, s));
+
+        // ---- backward
+        float* g = nullptr;                                   // d score / d (block output), already ReLU-masked
+        SISIC_TRY(get((size_t)B * C * h * w, &g));
+        SISIC_TRY(launch_score_head_bwd(r->ctx, logits, r->d_fc_w, act, g, B, C, h * w, r->num_classes, target, s));
+        put(logits);
+        for (int k = (int)r->blocks.size() - 1; k >= 0; --k) {
+            const Block& b = r->blocks[k];
+            const Saved& sv = saved[k];
+            const size_t n_mid = (size_t)B * b.conv2.cout * sv.bh * sv.bw;
+            float* tmp = nullptr;                             // conv2^T g, then the ReLU mask of t1
+            SISIC_TRY(get(n_mid, &tmp));
+            SISIC_TRY(conv_t(b.conv2, g, sv.bh, sv.bw, nullptr, tmp));
+            SISIC_TRY(launch_relu_bwd(r->ctx, tmp, sv.t1, tmp, (int64_t)n_mid, s));
+            const size_t n_in = (size_t)B * b.conv1.cin * sv.h * sv.w;
+            float* da = nullptr;
+            SISIC_TRY(get(n_in, &da));
+            if (!b.down.k) {
+                SISIC_TRY(conv_t(b.conv1, tmp, sv.bh, sv.bw, g, da));                 // + identity path
+            } else {
+                SISIC_TRY(conv_t(b.conv1, tmp, sv.bh, sv.bw, nullptr, da));           // stride 2: zero-insertion input
+                float* small = nullptr;
+                SISIC_TRY(get((size_t)B * b.down.cin * sv.bh * sv.bw, &small));
+                SISIC_TRY(conv_t(b.down, g, sv.bh, sv.bw, nullptr, small));           // 1x1 at the low resolution
+                SISIC_TRY(launch_scatter_add_even(r->ctx, da, small, B * b.down.cin, sv.h, sv.w, s));
+                put(small);
+            }
+            put(tmp);
+            put(g);
+            put(sv.t1);
+            put(sv.out);
+            if (k > 0) {                                       // ReLU of the previous block's output
+                SISIC_TRY(launch_relu_bwd(r->ctx, da, saved[k - 1].out, da, (int64_t)n_in, s));
+            }
+            g = da;
+        }
+        // g = d score / d (max-pool output)
+        float* dc1 = nullptr;
+        SISIC_TRY(get((size_t)B * 64 * c1h * c1w, &dc1));
+        SISIC_TRY(launch_maxpool_bwd(r->ctx, g, c1, dc1, B * 64, c1h, c1w, s));       // includes the stem's ReLU mask
+        put(g);
+        put(m);
+        put(c1);
+        float* dp = nullptr;
+        SISIC_TRY(get((size_t)B * 3 * S * S, &dp));
+        SISIC_TRY(launch_stem_bwd(r->ctx, dc1, r->stem.raw, dp, B, 64, c1h, c1w, S, S, s));
+        put(dc1);
+        SISIC_TRY(launch_preprocess_bwd(r->ctx, dp, x, grad_x, B, H, W, S, S, s));
+        put(dp);
         return SISIC_OK;
     };
     const int rc = body();

@@ -6,6 +6,10 @@
 * ``compute_shap_approximation``   -- XAI.py:1111-1177: 512 random 16x16-patch coalitions x classifier score.
                                      The reference runs 513 batch-1 forwards per image; here the coalition
                                      images are built on the GPU (``sisic_mask_patches``) and scored in batches.
+* ``compute_integrated_gradients`` -- XAI.py:1039-1084: captum IntegratedGradients (n_steps = 50, ``riemann_right``) of
+                                     the per-class score; all Riemann points go through ONE batched backward-to-input
+                                     pass of the HIP classifier (``sisic_resnet_input_gradient``), no autograd.
+* ``compute_gradient_attribution`` -- XAI.py:1086-1109: the plain input gradient (the reference's fallback).
 * ``time_shap_permutation``        -- README.md:171-207: Shapley values of the denoising STEPS with
                                      v(S) = F(Dec(x_T; S)) (transitions applied only on the steps in S, the other
                                      steps are skipped) and the unbiased permutation estimator.  The reference
@@ -49,6 +53,51 @@ def compute_time_shap(classifier: HipMelanomaClassifier, trajectory, timesteps: 
         normalized = np.ones_like(confidence_scores) / len(confidence_scores)
     raw = {"confidence_scores": confidence_scores, "probability_scores": prob_scores, "timesteps": list(timesteps)}
     return normalized, raw
+
+
+IG_N_STEPS = 50               # xai/XAI.py:240
+
+
+def make_baseline(image: torch.Tensor, baseline_type: str = "noise", generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """XAI.py:1010-1037: 'noise' = randn_like(image) * 0.1 (drawn on the CPU here so that it can be seeded), 'zero',
+    'blur' = avg_pool2d(kernel 31, stride 1, padding 15); anything else = zero."""
+    if baseline_type == "noise":
+        return (torch.randn(image.shape, generator=generator, dtype=torch.float32) * 0.1).to(image.device)
+    if baseline_type == "blur":
+        return torch.nn.functional.avg_pool2d(image, kernel_size=31, stride=1, padding=15)
+    return torch.zeros_like(image)
+
+
+@torch.no_grad()
+def compute_gradient_attribution(classifier: HipMelanomaClassifier, image: torch.Tensor, target_class: int) -> torch.Tensor:
+    """XAI.py:1086-1109: d get_per_class_score / d image."""
+    return classifier.input_gradient(image, target_class)[0]
+
+
+@torch.no_grad()
+def compute_integrated_gradients(classifier: HipMelanomaClassifier, image: torch.Tensor, target_class: int,
+                                 n_steps: int = IG_N_STEPS, baseline: Optional[torch.Tensor] = None,
+                                 baseline_type: str = "noise", generator: Optional[torch.Generator] = None,
+                                 max_batch: int = 128) -> torch.Tensor:
+    """XAI.py:1039-1084 (captum ``IntegratedGradients.attribute(image, baselines, n_steps, method='riemann_right')``
+    with ``forward_func = get_per_class_score``):
+        IG(x) = (x - x') * (1/n) * sum_{k=1..n} grad score(x' + (k/n)(x - x'))
+    image: [B,3,H,W]; the n*B Riemann points are differentiated in batches of ``max_batch`` images."""
+    image = image.to(classifier.device).to(torch.float32)
+    if baseline is None:
+        baseline = make_baseline(image, baseline_type, generator)
+    baseline = baseline.to(image.device).to(torch.float32)
+    B = image.shape[0]
+    alphas = torch.arange(1, n_steps + 1, dtype=torch.float32, device=image.device) / n_steps
+    diff = image - baseline
+    total = torch.zeros_like(image)
+    per = max(1, max_batch // B)                       # Riemann points per pass
+    for k0 in range(0, n_steps, per):
+        a = alphas[k0:k0 + per].view(-1, 1, 1, 1, 1)
+        pts = (baseline.unsqueeze(0) + a * diff.unsqueeze(0)).reshape((-1,) + tuple(image.shape[1:]))
+        g = classifier.input_gradient(pts, target_class)[0]
+        total += g.view((-1, B) + tuple(image.shape[1:])).sum(0)
+    return diff * total / n_steps
 
 
 def draw_patch_masks(n_samples: int, nh: int, nw: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:

@@ -108,6 +108,20 @@ def main():
     print(json.dumps({"config": "5b: Time-SHAP as coded (XAI.py:1179-1234), N=50 trajectory frames in one batch",
                       "ms_per_call": round(dt * 1e3, 3), "frames_per_sec": round(50 / dt, 1)}), flush=True)
 
+    # Integrated Gradients (XAI.py:1039-1084): 50 Riemann points of one 3x64x64 image = one batched backward-to-input
+    from synt_isic_amd.xai import compute_integrated_gradients
+    img = frames[:1]
+    base = torch.zeros_like(img)
+    compute_integrated_gradients(clf, img, 1, baseline=base)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        compute_integrated_gradients(clf, img, 1, baseline=base)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.reps
+    print(json.dumps({"config": "5c: Integrated Gradients, n_steps=50 (riemann_right), one 3x64x64 image: 50 forward+backward-to-input passes",
+                      "ms_per_image": round(dt * 1e3, 3), "gradients_per_sec": round(50 / dt, 1)}), flush=True)
+
 
 if __name__ == "__main__":
     main()
