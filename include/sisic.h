@@ -212,6 +212,13 @@ int sisic_resnet_forward(sisic_resnet*, const float* x, float* logits, int B, in
 int sisic_resnet_input_gradient(sisic_resnet*, const float* x, int B, int H, int W, int target,
                                 float* grad_x, float* logits_out, void* stream);
 
+/* Grad-CAM of the class logit on model.layer4[-1].conv2 as pytorch_grad_cam's GradCAM(target_layers=[...conv2]) with
+ * ClassifierOutputTarget(target) computes it in xai/XAI.py:2945-3035 (pre-processing included): cam = relu(sum_k
+ * mean(dlogit/dA_k) A_k), min-max scaled, bilinearly resized to 224x224, min-max scaled again.
+ * cam: dev [B,224,224]; logits_out: dev [B,n_classes] or NULL.                                            */
+int sisic_resnet_gradcam(sisic_resnet*, const float* x, int B, int H, int W, int target,
+                         float* cam, float* logits_out, void* stream);
+
 /* get_confidence / get_per_class_score (XAI.py:443-471): prob[b] = softmax(logits[b])[target],
  * logscore[b] = log(prob[b] + 1e-8); either output may be NULL.                               */
 int sisic_class_scores(sisic_ctx*, const float* logits, int B, int n_classes, int target, float* prob,

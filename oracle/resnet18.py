@@ -133,6 +133,57 @@ def integrated_gradients(sd, image: torch.Tensor, target_class: int, baseline: t
     return (image - baseline) * total / n_steps
 
 
+def _scale_cam_image(cam: torch.Tensor, target_size=None) -> torch.Tensor:
+    """pytorch_grad_cam.utils.image.scale_cam_image per image: (img - min) / (1e-7 + max), then (optionally) the bilinear
+    resize cv2.resize performs (INTER_LINEAR on float32 = half-pixel centres, i.e. align_corners=False)."""
+    out = []
+    for img in cam:
+        img = img - img.min()
+        img = img / (1e-7 + img.max())
+        if target_size is not None:
+            img = F.interpolate(img[None, None], size=target_size, mode="bilinear", align_corners=False)[0, 0]
+        out.append(img)
+    return torch.stack(out)
+
+
+def grad_cam(sd, x: torch.Tensor, target_class: int, size: int = CLASSIFIER_IMAGE_SIZE) -> torch.Tensor:
+    """pytorch_grad_cam.GradCAM(model, target_layers=[model.layer4[-1].conv2]) with ClassifierOutputTarget(target_class)
+    on the pre-processed image, as called at XAI.py:2992-3020: activations A = the conv2 output (before bn2), gradients
+    of the raw class logit w.r.t. A, weights = their spatial mean, cam = relu(sum_k w_k A_k); scale_cam_image with the
+    resize to (224, 224), and the aggregation's second scale_cam_image.  Returns [B, 224, 224] in [0, 1]."""
+    p = "model."
+    with torch.enable_grad():
+        h = preprocess_for_classifier(x)
+        h = F.conv2d(h, sd[p + "conv1.weight"], None, stride=2, padding=3)
+        h = F.relu(_bn(sd, p + "bn1", h))
+        h = F.max_pool2d(h, kernel_size=3, stride=2, padding=1)
+        A = None
+        for l in range(4):
+            for j in range(2):
+                stride = 2 if (l > 0 and j == 0) else 1
+                base = f"{p}layer{l + 1}.{j}"
+                identity = h
+                out = F.conv2d(h, sd[base + ".conv1.weight"], None, stride=stride, padding=1)
+                out = F.relu(_bn(sd, base + ".bn1", out))
+                out = F.conv2d(out, sd[base + ".conv2.weight"], None, stride=1, padding=1)
+                if l == 3 and j == 1:
+                    A = out.detach().clone().requires_grad_(True)       # the hooked activation
+                    out = A
+                out = _bn(sd, base + ".bn2", out)
+                if base + ".downsample.0.weight" in sd:
+                    identity = F.conv2d(h, sd[base + ".downsample.0.weight"], None, stride=stride)
+                    identity = _bn(sd, base + ".downsample.1", identity)
+                h = F.relu(out + identity)
+        feat = F.adaptive_avg_pool2d(h, 1).flatten(1)
+        logits = F.linear(feat, sd[p + "fc.weight"], sd[p + "fc.bias"])
+        (G,) = torch.autograd.grad(logits[:, target_class].sum(), A)
+    weights = G.mean(dim=(2, 3), keepdim=True)
+    cam = torch.clamp((weights * A.detach()).sum(dim=1), min=0)                 # [B, 7, 7]
+    cam = _scale_cam_image(cam, (size, size))                                   # compute_cam_per_layer
+    cam = torch.clamp(cam, min=0)
+    return _scale_cam_image(cam)                                                # aggregate_multi_layers
+
+
 def expand_patch_mask(patch_mask: torch.Tensor, H: int, W: int, patch: int) -> torch.Tensor:
     """XAI.py:1149-1157: boolean patch grid -> boolean pixel mask (pixels beyond the grid stay False)."""
     full = torch.zeros(H, W, dtype=torch.bool)

@@ -207,5 +207,22 @@ class HipMelanomaClassifier:
                                                       C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
         return grad, logits
 
+    def grad_cam(self, x: torch.Tensor, target_class: int):
+        """(cam [B,224,224] in [0,1], logits): pytorch_grad_cam's GradCAM on ``model.layer4[-1].conv2`` for the raw class
+        logit, as xai/XAI.py:2945-3035 calls it on each trajectory frame (sisic_resnet_gradcam)."""
+        h = self.handle
+        if x.device != self._device:
+            x = x.to(self._device)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"classifier input must be [B,3,H,W], got {tuple(x.shape)}")
+        x = x.detach().to(torch.float32).contiguous()
+        B, _, H, W = x.shape
+        cam = torch.empty((B, 224, 224), dtype=torch.float32, device=x.device)
+        logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=x.device)
+        check(_lib.load().sisic_resnet_gradcam(h, x.data_ptr(), B, H, W, int(target_class), cam.data_ptr(),
+                                               logits.data_ptr(),
+                                               C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return cam, logits
+
     def predict(self, x: torch.Tensor) -> torch.Tensor:
         return torch.argmax(self.forward(x), dim=1)

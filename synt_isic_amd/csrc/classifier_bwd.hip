@@ -264,3 +264,105 @@ int launch_preprocess_bwd(sisic_ctx* ctx, const float* dp, const float* x, float
 }
 
 }  // namespace sisic
+
+namespace sisic {
+
+// out = relu(y + identity)   (the last block's tail when its conv2 output is kept for Grad-CAM)
+__global__ void __launch_bounds__(256)
+add_relu_kernel(const float* __restrict__ y, const float* __restrict__ identity, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = fmaxf(y[i] + identity[i], 0.0f);
+}
+
+int launch_add_relu(sisic_ctx* ctx, const float* y, const float* identity, float* out, int64_t n, hipStream_t s) {
+    SISIC_REQUIRE(y && identity && out && n > 0, "add_relu: bad arguments");
+    ProfileScope prof(ctx, s, PK_OTHER, 12.0 * n, 0.0);
+    hipLaunchKernelGGL(add_relu_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 16384)), dim3(256), 0, s, y, identity, out, n);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// Grad-CAM (Selvaraju et al.) on layer4[-1].conv2 for the raw class logit, as pytorch_grad_cam's GradCAM computes it
+// (xai/XAI.py:2945-3035: target_layers=[model.layer4[-1].conv2], ClassifierOutputTarget(c)):
+//   A = conv2 output BEFORE its BatchNorm, G = d logit_c / d A, alpha_k = mean_hw G_k,
+//   cam = relu(sum_k alpha_k A_k) -> (cam - min) / (1e-7 + max) -> bilinear to SxS -> (.. - min) / (1e-7 + max) again.
+// With BatchNorm folded, Y = s A + b is what the convolution produced and d logit / d Y = W_fc[c,k] / HW * [out > 0], so
+//   alpha_k A_k = (W_fc[c,k] / HW) * frac_k * (Y_k - b_k),   frac_k = share of positive outputs in channel k
+// (the BatchNorm scale s_k cancels).  One workgroup per image.
+__global__ void __launch_bounds__(256)
+gradcam_kernel(const float* __restrict__ y, const float* __restrict__ outp, const float* __restrict__ fc_w,
+               const float* __restrict__ bias, float* __restrict__ cam, int C, int h, int w, int S, int target) {
+    extern __shared__ float sm[];
+    float* coef = sm;                  // [C]
+    float* cam_lo = sm + C;            // [h*w]
+    float* red = cam_lo + h * w;       // [512] reduction scratch (min, max)
+    const int b = blockIdx.x, tid = threadIdx.x, HW = h * w;
+    const float* yb = y + (size_t)b * C * HW;
+    const float* ob = outp + (size_t)b * C * HW;
+    for (int k = tid; k < C; k += blockDim.x) {
+        int pos = 0;
+        for (int p = 0; p < HW; ++p) pos += ob[(size_t)k * HW + p] > 0.0f ? 1 : 0;
+        coef[k] = fc_w[(size_t)target * C + k] / (float)HW * ((float)pos / (float)HW);
+    }
+    __syncthreads();
+    for (int p = tid; p < HW; p += blockDim.x) {
+        float a = 0.0f;
+        for (int k = 0; k < C; ++k) a += coef[k] * (yb[(size_t)k * HW + p] - bias[k]);
+        cam_lo[p] = fmaxf(a, 0.0f);
+    }
+    __syncthreads();
+    auto block_minmax = [&](float vmin, float vmax, float* omin, float* omax) {
+        red[tid] = vmin;
+        red[256 + tid] = vmax;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                red[tid] = fminf(red[tid], red[tid + off]);
+                red[256 + tid] = fmaxf(red[256 + tid], red[256 + tid + off]);
+            }
+            __syncthreads();
+        }
+        *omin = red[0];
+        *omax = red[256];
+        __syncthreads();
+    };
+    float mn = INFINITY, mx = -INFINITY;
+    for (int p = tid; p < HW; p += blockDim.x) { mn = fminf(mn, cam_lo[p]); mx = fmaxf(mx, cam_lo[p]); }
+    float lo_min, lo_max;
+    block_minmax(mn, mx, &lo_min, &lo_max);
+    for (int p = tid; p < HW; p += blockDim.x) cam_lo[p] = (cam_lo[p] - lo_min) / (1e-7f + (lo_max - lo_min));
+    __syncthreads();
+    // bilinear, half-pixel centres, clamped source index (cv2.INTER_LINEAR / align_corners=False when upscaling)
+    float* cb = cam + (size_t)b * S * S;
+    const float sh = (float)h / (float)S, sw = (float)w / (float)S;
+    mn = INFINITY; mx = -INFINITY;
+    for (int i = tid; i < S * S; i += blockDim.x) {
+        const int Y = i / S, X = i % S;
+        const float fy = fmaxf(sh * ((float)Y + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sw * ((float)X + 0.5f) - 0.5f, 0.0f);
+        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float top = cam_lo[y0 * w + x0] * (1.0f - lx) + cam_lo[y0 * w + x1] * lx;
+        const float bot = cam_lo[y1 * w + x0] * (1.0f - lx) + cam_lo[y1 * w + x1] * lx;
+        const float v = top * (1.0f - ly) + bot * ly;
+        cb[i] = v;
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    float hi_min, hi_max;
+    block_minmax(mn, mx, &hi_min, &hi_max);
+    for (int i = tid; i < S * S; i += blockDim.x) cb[i] = (cb[i] - hi_min) / (1e-7f + (hi_max - hi_min));
+}
+
+int launch_gradcam(sisic_ctx* ctx, const float* y, const float* outp, const float* fc_w, const float* bias, float* cam, int B,
+                   int C, int h, int w, int S, int target, hipStream_t s) {
+    SISIC_REQUIRE(y && outp && fc_w && bias && cam && B > 0 && C > 0 && h > 0 && w > 0 && S > 0, "gradcam: bad arguments");
+    const size_t lds = ((size_t)C + (size_t)h * w + 512) * sizeof(float);
+    SISIC_REQUIRE(lds <= 64 * 1024, "gradcam: %d channels x %dx%d do not fit the scratch", C, h, w);
+    ProfileScope prof(ctx, s, PK_OTHER, 8.0 * B * C * h * w + 4.0 * B * S * S, 0.0);
+    hipLaunchKernelGGL(gradcam_kernel, dim3(B), dim3(256), lds, s, y, outp, fc_w, bias, cam, C, h, w, S, target);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+}  // namespace sisic

@@ -106,6 +106,9 @@ int launch_stem_bwd(sisic_ctx*, const float* g, const float* w_oihw, float* dp, 
                     hipStream_t s);
 int launch_preprocess_bwd(sisic_ctx*, const float* dp, const float* x, float* dx, int B, int H, int W, int OH, int OW,
                           hipStream_t s);
+int launch_add_relu(sisic_ctx*, const float* y, const float* identity, float* out, int64_t n, hipStream_t s);
+int launch_gradcam(sisic_ctx*, const float* y, const float* outp, const float* fc_w, const float* bias, float* cam, int B, int C,
+                   int h, int w, int S, int target, hipStream_t s);
 int conv_stats_slots(const sisic_conv_args& a);
 int launch_gn_finalize(sisic_ctx*, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
                        int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,

@@ -460,6 +460,95 @@ int sisic_resnet_input_gradient(sisic_resnet* r, const float* x, int B, int H, i
     return rc;
 }
 
+// Grad-CAM on layer4[-1].conv2 for the raw logit of `target` (xai/XAI.py:2945-3035; see gradcam_kernel): the forward
+// pass with the last block's conv2 (+BatchNorm) output kept before the residual add, then one small kernel per image.
+// cam: dev [B,224,224] in [0,1] (pytorch_grad_cam's double min-max scaling), logits_out: dev [B,n_classes] or NULL.
+int sisic_resnet_gradcam(sisic_resnet* r, const float* x, int B, int H, int W, int target, float* cam, float* logits_out,
+                         void* stream) {
+    SISIC_REQUIRE(r && x && cam && B > 0 && H > 0 && W > 0, "resnet_gradcam: bad arguments");
+    SISIC_REQUIRE(target >= 0 && target < r->num_classes, "resnet_gradcam: class %d of %d", target, r->num_classes);
+    if (!r->loaded) {
+        set_error("resnet_gradcam called before sisic_resnet_load");
+        return SISIC_ESTATE;
+    }
+    SISIC_HIP(hipSetDevice(r->ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<float*> live;
+    auto get = [&](size_t floats, float** p) {
+        const int rc = pool_get(r, floats, p);
+        if (rc == SISIC_OK) live.push_back(*p);
+        return rc;
+    };
+    auto put = [&](float* p) {
+        pool_put(r, p);
+        live.erase(std::remove(live.begin(), live.end(), p), live.end());
+    };
+    auto body = [&]() -> int {
+        const int S = 224;
+        SISIC_REQUIRE(H <= S && W <= S, "resnet_gradcam: input %dx%d larger than the classifier's %dx%d", H, W, S, S);
+        float* pre = nullptr;
+        SISIC_TRY(get((size_t)B * 3 * S * S, &pre));
+        SISIC_TRY(launch_preprocess(r->ctx, x, pre, B, H, W, S, S, s));
+        int h = S, w = S;
+        int oh = out_dim(h, 7, 2), ow = out_dim(w, 7, 2);
+        float* c1 = nullptr;
+        SISIC_TRY(get((size_t)B * 64 * oh * ow, &c1));
+        SISIC_TRY(run_conv(r, r->stem, pre, B, h, w, nullptr, true, c1, s));
+        put(pre);
+        h = oh; w = ow;
+        oh = out_dim(h, 3, 2); ow = out_dim(w, 3, 2);
+        float* act = nullptr;
+        SISIC_TRY(get((size_t)B * 64 * oh * ow, &act));
+        SISIC_TRY(launch_maxpool(r->ctx, c1, act, B, 64, h, w, s));
+        put(c1);
+        h = oh; w = ow;
+        float* ylast = nullptr;
+        for (size_t k = 0; k < r->blocks.size(); ++k) {
+            const Block& b = r->blocks[k];
+            const bool last = k + 1 == r->blocks.size();
+            const int bh = out_dim(h, 3, b.conv1.stride), bw = out_dim(w, 3, b.conv1.stride);
+            float* t1 = nullptr;
+            SISIC_TRY(get((size_t)B * b.conv1.cout * bh * bw, &t1));
+            SISIC_TRY(run_conv(r, b.conv1, act, B, h, w, nullptr, true, t1, s));
+            const float* identity = act;
+            float* ds = nullptr;
+            if (b.down.k) {
+                SISIC_TRY(get((size_t)B * b.down.cout * bh * bw, &ds));
+                SISIC_TRY(run_conv(r, b.down, act, B, h, w, nullptr, false, ds, s));
+                identity = ds;
+            }
+            float* t2 = nullptr;
+            const size_t n_out = (size_t)B * b.conv2.cout * bh * bw;
+            SISIC_TRY(get(n_out, &t2));
+            if (!last) {
+                SISIC_TRY(run_conv(r, b.conv2, t1, B, bh, bw, identity, true, t2, s));
+            } else {                                           // keep bn2(conv2(.)) on its own, then relu(. + identity)
+                SISIC_TRY(get(n_out, &ylast));
+                SISIC_TRY(run_conv(r, b.conv2, t1, B, bh, bw, nullptr, false, ylast, s));
+                SISIC_TRY(launch_add_relu(r->ctx, ylast, identity, t2, (int64_t)n_out, s));
+            }
+            put(t1);
+            if (ds) put(ds);
+            put(act);
+            act = t2; h = bh; w = bw;
+        }
+        const FoldedConv& c2 = r->blocks.back().conv2;
+        float* logits = nullptr;
+        SISIC_TRY(get((size_t)B * r->num_classes, &logits));
+        SISIC_TRY(launch_avgpool_fc(r->ctx, act, r->d_fc_w, r->d_fc_b, logits, B, c2.cout, h * w, r->num_classes, s));
+        if (logits_out)
+            SISIC_HIP(hipMemcpyAsync(logits_out, logits, (size_t)B * r->num_classes * sizeof(float), hipMemcpyDeviceToDevice, s));
+        put(logits);
+        SISIC_TRY(launch_gradcam(r->ctx, ylast, act, r->d_fc_w, c2.bias, cam, B, c2.cout, h, w, S, target, s));
+        put(ylast);
+        put(act);
+        return SISIC_OK;
+    };
+    const int rc = body();
+    for (float* p : live) pool_put(r, p);
+    return rc;
+}
+
 int sisic_class_scores(sisic_ctx* ctx, const float* logits, int B, int n_classes, int target, float* prob,
                        float* logscore, void* stream) {
     SISIC_REQUIRE(ctx, "class_scores: null context");

@@ -9,6 +9,8 @@
 * ``compute_integrated_gradients`` -- XAI.py:1039-1084: captum IntegratedGradients (n_steps = 50, ``riemann_right``) of
                                      the per-class score; all Riemann points go through ONE batched backward-to-input
                                      pass of the HIP classifier (``sisic_resnet_input_gradient``), no autograd.
+* ``compute_grad_cam``             -- XAI.py:2945-3134: Grad-CAM on ``layer4[-1].conv2`` for every trajectory frame (ONE
+                                     batch instead of a GradCAM call per frame) + the normalised mean map.
 * ``compute_gradient_attribution`` -- XAI.py:1086-1109: the plain input gradient (the reference's fallback).
 * ``time_shap_permutation``        -- README.md:171-207: Shapley values of the denoising STEPS with
                                      v(S) = F(Dec(x_T; S)) (transitions applied only on the steps in S, the other
@@ -98,6 +100,20 @@ def compute_integrated_gradients(classifier: HipMelanomaClassifier, image: torch
         g = classifier.input_gradient(pts, target_class)[0]
         total += g.view((-1, B) + tuple(image.shape[1:])).sum(0)
     return diff * total / n_steps
+
+
+@torch.no_grad()
+def compute_grad_cam(classifier: HipMelanomaClassifier, trajectory, timesteps: Sequence[float], target_class: int) -> Dict:
+    """XAI.py:2945-3134: {"t_<timestep>": cam (224,224) numpy in [0,1]} for every frame, and "summary": the mean of the
+    frames' maps min-max normalised with eps 1e-8 (``gradcam_summary``, :3102-3104)."""
+    frames = _as_batch(trajectory)
+    if frames.shape[0] != len(timesteps):
+        raise ValueError(f"{frames.shape[0]} frames but {len(timesteps)} timesteps")
+    cams = classifier.grad_cam(frames, target_class)[0].cpu().numpy()
+    out = {f"t_{float(t):.0f}": cams[i] for i, t in enumerate(timesteps)}
+    mean = cams.mean(axis=0)
+    out["summary"] = (mean - mean.min()) / (mean.max() - mean.min() + 1e-8)
+    return out
 
 
 def draw_patch_masks(n_samples: int, nh: int, nw: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:

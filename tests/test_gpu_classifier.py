@@ -295,3 +295,28 @@ def test_integrated_gradients_matches_oracle_and_completeness(clf, clf_sd):
     # zero and blur baselines of _get_baseline
     assert torch.count_nonzero(xai.make_baseline(x, "zero")) == 0
     assert xai.make_baseline(x, "blur").shape == x.shape
+
+
+def test_grad_cam_matches_oracle(clf, clf_sd):
+    """pytorch_grad_cam-style Grad-CAM on layer4[-1].conv2 (XAI.py:2945-3035) against the autograd restatement: maps in
+    [0,1] with their extremes attained, <= 2e-3 apart (a flipped ReLU mask at the 7x7 level moves a channel weight
+    by 1/49 of its value), logits as the ordinary forward."""
+    from oracle import resnet18 as ores
+    from synt_isic_amd import xai
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(5, 3, 64, 64, generator=g) * 1.8 - 0.9
+    cam, logits = clf.grad_cam(x.to(DEV), NV)
+    ref = ores.grad_cam(clf_sd, x, NV)
+    assert cam.shape == (5, 224, 224) and torch.equal(logits, clf(x.to(DEV)))
+    c = cam.cpu()
+    assert c.min().item() >= 0.0 and c.max().item() <= 1.0
+    assert torch.all(c.flatten(1).min(1).values == 0) and torch.all(c.flatten(1).max(1).values > 0.999)
+    assert (c - ref).abs().max().item() <= 2e-3, (c - ref).abs().max().item()
+    # 128x128 frames (the reference's trajectory size) and the per-trajectory summary
+    frames = [torch.rand(1, 3, 128, 128, generator=g) * 1.6 - 0.8 for _ in range(4)]
+    res = xai.compute_grad_cam(clf, frames, [980, 600, 300, 0], NV)
+    assert sorted(res) == ["summary", "t_0", "t_300", "t_600", "t_980"]
+    ref4 = ores.grad_cam(clf_sd, torch.cat(frames), NV).numpy()
+    assert np.abs(res["t_600"] - ref4[1]).max() <= 2e-3
+    mean = ref4.mean(0)
+    assert np.abs(res["summary"] - (mean - mean.min()) / (mean.max() - mean.min() + 1e-8)).max() <= 4e-3
