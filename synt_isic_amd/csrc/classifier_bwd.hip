@@ -139,65 +139,101 @@ int launch_maxpool_bwd(sisic_ctx* ctx, const float* dm, const float* xin, float*
 
 // Transposed 7x7 stride-2 padding-3 convolution, 64 -> 3 channels:
 //   dp[b,ci,Y,X] = sum_{co,ky,kx} W[co,ci,ky,kx] * g[b,co,(Y+3-ky)/2,(X+3-kx)/2]   over the taps for which both
-//   quotients are integers inside the map.  W = the BN-folded OIHW stem filter.  One thread per (b, Y, X); the
-//   filter sits in LDS as [co][ky][kx][ci(4)] so that the three input channels of a tap are one ds_read_b128.
+//   quotients are integers inside the map.  W = the BN-folded OIHW stem filter.
+// A workgroup owns a 32x32 output tile of one image and walks the 64 channels in chunks of 8: the 19x19 patch of g
+// the tile can reach and the chunk's filters ([co][ky][kx][ci(4)]: the three input channels of a tap are one
+// ds_read_b128) sit in LDS; a thread produces a 2x2 block of pixels, i.e. all four tap parities, so every g value it
+// reads is used by four pixels.
+constexpr int SB_T = 32, SB_G = SB_T / 2 + 3, SB_CC = 8;       // output tile, g patch edge (19), channels per chunk
+
 __global__ void __launch_bounds__(256)
 stem_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dp, int CO, int OH, int OW,
-                int H, int W, int64_t total) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];      // [CO][49][4]
-    for (int i = threadIdx.x; i < CO * 49; i += blockDim.x) {
-        const int co = i / 49, tap = i % 49;
-        wl[i * 4 + 0] = w[((size_t)co * 3 + 0) * 49 + tap];
-        wl[i * 4 + 1] = w[((size_t)co * 3 + 1) * 49 + tap];
-        wl[i * 4 + 2] = w[((size_t)co * 3 + 2) * 49 + tap];
-        wl[i * 4 + 3] = 0.0f;
-    }
-    __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int X = (int)(i % W);
-        const int64_t r = i / W;
-        const int Y = (int)(r % H);
-        const int64_t b = r / H;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-        const int ky0 = (Y + 3) & 1, kx0 = (X + 3) & 1;              // taps with the right parity
-        for (int co = 0; co < CO; ++co) {
-            const float* gp = g + ((size_t)b * CO + co) * OH * OW;
-            for (int ky = ky0; ky < 7; ky += 2) {
-                const int oy = (Y + 3 - ky) >> 1;
-                if (oy < 0 || oy >= OH) continue;
-                for (int kx = kx0; kx < 7; kx += 2) {
-                    const int ox = (X + 3 - kx) >> 1;
-                    if (ox < 0 || ox >= OW) continue;
-                    const float gv = gp[(size_t)oy * OW + ox];
-                    const float4 wv = *reinterpret_cast<const float4*>(&wl[((co * 7 + ky) * 7 + kx) * 4]);
-                    a0 += gv * wv.x;
-                    a1 += gv * wv.y;
-                    a2 += gv * wv.z;
+                int H, int W, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) float wl[SB_CC * 49 * 4];
+    __shared__ float gl[SB_CC * SB_G * SB_G];
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int Y0 = ty * SB_T, X0 = tx * SB_T;
+    const int oy_lo = Y0 / 2 - 1, ox_lo = X0 / 2 - 1;           // first g row / column any pixel of the tile can reach
+    const int tid = threadIdx.x;
+    const int py = tid / 16, px = tid % 16;                        // 2x2 pixel block (2*py .. 2*py+1, 2*px .. 2*px+1)
+    float acc[2][2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[i][j][c] = 0.0f;
+    for (int c0 = 0; c0 < CO; c0 += SB_CC) {
+        __syncthreads();
+        for (int i = tid; i < SB_CC * 49; i += 256) {
+            const int co = c0 + i / 49, tap = i % 49;
+            const bool v = co < CO;
+            wl[i * 4 + 0] = v ? w[((size_t)co * 3 + 0) * 49 + tap] : 0.0f;
+            wl[i * 4 + 1] = v ? w[((size_t)co * 3 + 1) * 49 + tap] : 0.0f;
+            wl[i * 4 + 2] = v ? w[((size_t)co * 3 + 2) * 49 + tap] : 0.0f;
+            wl[i * 4 + 3] = 0.0f;
+        }
+        for (int i = tid; i < SB_CC * SB_G * SB_G; i += 256) {
+            const int cc = i / (SB_G * SB_G), r = i % (SB_G * SB_G);
+            const int oy = oy_lo + r / SB_G, ox = ox_lo + r % SB_G;
+            const bool v = c0 + cc < CO && oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+            gl[i] = v ? g[(((size_t)b * CO + c0 + cc) * OH + oy) * OW + ox] : 0.0f;
+        }
+        __syncthreads();
+        // pixel (2py+i, 2px+j) of the tile: Y = Y0 + 2py + i; taps ky with (Y+3-ky) even: ky = (i+1)%2, +2, ...;
+        // g row oy = (Y + 3 - ky) / 2 = Y0/2 + py + (i + 3 - ky) / 2   ->  patch row py + 1 + (i + 3 - ky) / 2  in [0, 18]
+        for (int cc = 0; cc < SB_CC; ++cc) {
+            const float* gp = gl + cc * SB_G * SB_G;
+            const float* wp = wl + cc * 49 * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int ky = (i + 1) & 1; ky < 7; ky += 2) {
+                    const int gr = py + 1 + (i + 3 - ky) / 2;      // (i + 3 - ky) is even and in [-2, 4]
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int kx = (j + 1) & 1; kx < 7; kx += 2) {
+                            const int gc = px + 1 + (j + 3 - kx) / 2;
+                            const float gv = gp[gr * SB_G + gc];
+                            const float4 wv = *reinterpret_cast<const float4*>(&wp[(ky * 7 + kx) * 4]);
+                            acc[i][j][0] += gv * wv.x;
+                            acc[i][j][1] += gv * wv.y;
+                            acc[i][j][2] += gv * wv.z;
+                        }
+                    }
                 }
             }
         }
-        const size_t HWp = (size_t)H * W;
-        float* o = dp + (size_t)b * 3 * HWp + (size_t)Y * W + X;
-        o[0] = a0;
-        o[HWp] = a1;
-        o[2 * HWp] = a2;
     }
+    const size_t HWp = (size_t)H * W;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int Y = Y0 + 2 * py + i, X = X0 + 2 * px + j;
+            if (Y < H && X < W) {
+                float* o = dp + (size_t)b * 3 * HWp + (size_t)Y * W + X;
+                o[0] = acc[i][j][0];
+                o[HWp] = acc[i][j][1];
+                o[2 * HWp] = acc[i][j][2];
+            }
+        }
 }
 
 int launch_stem_bwd(sisic_ctx* ctx, const float* g, const float* w_oihw, float* dp, int B, int CO, int OH, int OW, int H,
                     int W, hipStream_t s) {
-    SISIC_REQUIRE(g && w_oihw && dp && B > 0 && CO > 0 && CO * 49 * 16 <= 160 * 1024, "stem_bwd: bad arguments");
+    SISIC_REQUIRE(g && w_oihw && dp && B > 0 && CO > 0, "stem_bwd: bad arguments");
     SISIC_REQUIRE(OH == (H + 6 - 7) / 2 + 1 && OW == (W + 6 - 7) / 2 + 1, "stem_bwd: %dx%d is not the stem output of %dx%d", OH, OW, H, W);
-    const int64_t total = (int64_t)B * H * W;
-    const size_t lds = (size_t)CO * 49 * 4 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    const int tiles_x = (W + SB_T - 1) / SB_T, tiles_y = (H + SB_T - 1) / SB_T;
+    const int64_t nwg = (int64_t)B * tiles_x * tiles_y;
+    SISIC_REQUIRE(nwg < (int64_t(1) << 31), "stem_bwd: grid too large");
     ProfileScope prof(ctx, s, PK_OTHER, 4.0 * B * ((double)CO * OH * OW + 3.0 * H * W), 2.0 * B * 3.0 * CO * 49.0 * OH * OW);
-    hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), lds, s, g, w_oihw,
-                       dp, CO, OH, OW, H, W, total);
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3((unsigned)nwg), dim3(256), 0, s, g, w_oihw, dp, CO, OH, OW, H, W, tiles_x, tiles_y);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
