@@ -35,7 +35,7 @@ def sampling(batch, size, steps, warmup):
     model = s.add_model("NV", synthetic_unet_state_dict())
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, 3, size, size, generator=g).to(dev)
-    z = torch.randn(steps, batch, 3, size, size, generator=g).to(dev)
+    z = torch.randn(max(steps, warmup, 3), batch, 3, size, size, generator=g).to(dev)
 
     def run(k):
         sched = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
