@@ -219,6 +219,12 @@ int sisic_resnet_input_gradient(sisic_resnet*, const float* x, int B, int H, int
 int sisic_resnet_gradcam(sisic_resnet*, const float* x, int B, int H, int W, int target,
                          float* cam, float* logits_out, void* stream);
 
+/* Bytes of activation workspace the handle currently keeps resident (its pool).  The pool is sized for the last
+ * (B,H,W) seen and released when the shape changes, so this does not grow with the history of batch sizes
+ * (the GUI's memory poll, main.py:230-253, would otherwise watch it climb).                                  */
+int64_t sisic_resnet_workspace_bytes(const sisic_resnet*);
+int64_t sisic_unet_workspace_bytes(const sisic_unet*);
+
 /* get_confidence / get_per_class_score (XAI.py:443-471): prob[b] = softmax(logits[b])[target],
  * logscore[b] = log(prob[b] + 1e-8); either output may be NULL.                               */
 int sisic_class_scores(sisic_ctx*, const float* logits, int B, int n_classes, int target, float* prob,
@@ -233,7 +239,7 @@ int sisic_mask_patches(sisic_ctx*, const float* image, const uint8_t* masks, flo
  * accumulated per class; reading synchronises the stream.                           */
 int sisic_profile_enable(sisic_ctx*, int on);
 /* kind: 0 = conv3x3, 1 = conv1x1, 2 = groupnorm stats, 3 = attention, 4 = ddpm step,
- *       5 = other.  Returns accumulated milliseconds, launches, algorithmic bytes, algorithmic flops (2*MAC of the
+ *       5 = other, 6 = the dominant kernel alone (conv_winograd_kernel<1,8,8,*,16,false>, a subset of kind 0).  Returns accumulated milliseconds, launches, algorithmic bytes, algorithmic flops (2*MAC of the
  *       direct form) and the flops actually issued to the matrix pipe (fewer for Winograd launches).  */
 int sisic_profile_read(sisic_ctx*, int kind, double* ms, int64_t* launches, double* bytes, double* flops,
                        double* flops_executed);

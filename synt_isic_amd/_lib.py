@@ -96,6 +96,8 @@ SIGNATURES = {
                                               C.c_void_p, C.c_void_p]),
     "sisic_resnet_gradcam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "sisic_resnet_workspace_bytes": (C.c_int64, [C.c_void_p]),
+    "sisic_unet_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "sisic_class_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p]),
     "sisic_mask_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

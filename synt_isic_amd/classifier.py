@@ -141,6 +141,25 @@ class HipMelanomaClassifier:
         return self._handle
 
     # ---- forward --------------------------------------------------------------------------------
+    # Frames per library call.  The callers in xai.py hand over whole trajectories (N frames = N inference steps, up to
+    # 1000) and coalition sets; the library's activation workspace scales with the batch of a call (stem output:
+    # 3.2 MB per image, the backward passes keep every block's activations), so the batch of one call is capped and
+    # longer inputs are walked in chunks.  Rows do not depend on the chunking (no kernel choice depends on the batch).
+    max_forward_batch = 512
+    max_backward_batch = 128
+
+    @staticmethod
+    def _chunks(total: int, cap: int):
+        lo = 0
+        while lo < total:
+            n = min(cap, total - lo)
+            yield lo, n
+            lo += n
+
+    def workspace_bytes(self) -> int:
+        """activation workspace the library keeps for this model (released when the input shape changes)"""
+        return int(_lib.load().sisic_resnet_workspace_bytes(self._handle)) if self._handle is not None else 0
+
     @torch.no_grad()
     def forward(self, x: torch.Tensor, preprocessed: bool = False) -> torch.Tensor:
         """logits [B,num_classes].  x: [B,3,H,W] in [-1,1] (H,W <= 224); it is moved to the model's device like
@@ -153,8 +172,10 @@ class HipMelanomaClassifier:
         x = x.to(torch.float32).contiguous()
         B, _, H, W = x.shape
         out = torch.empty((B, self.num_classes), dtype=torch.float32, device=x.device)
-        check(_lib.load().sisic_resnet_forward(h, x.data_ptr(), out.data_ptr(), B, H, W, 0 if preprocessed else 1,
-                                               C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        for lo, n in self._chunks(B, self.max_forward_batch):
+            check(_lib.load().sisic_resnet_forward(h, x[lo:].data_ptr(), out[lo:].data_ptr(), n, H, W,
+                                                   0 if preprocessed else 1, stream))
         return out
 
     __call__ = forward
@@ -202,9 +223,10 @@ class HipMelanomaClassifier:
         B, _, H, W = x.shape
         grad = torch.empty_like(x)
         logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=x.device)
-        check(_lib.load().sisic_resnet_input_gradient(h, x.data_ptr(), B, H, W, int(target_class), grad.data_ptr(),
-                                                      logits.data_ptr(),
-                                                      C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        for lo, n in self._chunks(B, self.max_backward_batch):
+            check(_lib.load().sisic_resnet_input_gradient(h, x[lo:].data_ptr(), n, H, W, int(target_class),
+                                                          grad[lo:].data_ptr(), logits[lo:].data_ptr(), stream))
         return grad, logits
 
     def grad_cam(self, x: torch.Tensor, target_class: int):
@@ -219,9 +241,10 @@ class HipMelanomaClassifier:
         B, _, H, W = x.shape
         cam = torch.empty((B, 224, 224), dtype=torch.float32, device=x.device)
         logits = torch.empty((B, self.num_classes), dtype=torch.float32, device=x.device)
-        check(_lib.load().sisic_resnet_gradcam(h, x.data_ptr(), B, H, W, int(target_class), cam.data_ptr(),
-                                               logits.data_ptr(),
-                                               C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        for lo, n in self._chunks(B, self.max_backward_batch):
+            check(_lib.load().sisic_resnet_gradcam(h, x[lo:].data_ptr(), n, H, W, int(target_class),
+                                                   cam[lo:].data_ptr(), logits[lo:].data_ptr(), stream))
         return cam, logits
 
     def predict(self, x: torch.Tensor) -> torch.Tensor:

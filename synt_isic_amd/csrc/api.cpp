@@ -29,17 +29,21 @@ static hipEvent_t take_event(sisic_ctx* ctx) {
     return e;
 }
 
-ProfileScope::ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops, double flops_exec)
+ProfileScope::ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops, double flops_exec, int kind2)
     : ctx(c), stream(s) {
     if (!c || !c->profiling) return;
     ev.start = take_event(c);
     ev.stop = take_event(c);
     ev.kind = kind;
+    ev.kind2 = kind2;
     if (!ev.start || !ev.stop) return;
-    c->prof[kind].bytes += bytes;
-    c->prof[kind].flops += flops;
-    c->prof[kind].flops_exec += (flops_exec < 0.0) ? flops : flops_exec;
-    c->prof[kind].launches += 1;
+    for (int k : {kind, kind2}) {
+        if (k < 0) continue;
+        c->prof[k].bytes += bytes;
+        c->prof[k].flops += flops;
+        c->prof[k].flops_exec += (flops_exec < 0.0) ? flops : flops_exec;
+        c->prof[k].launches += 1;
+    }
     (void)hipEventRecord(ev.start, s);
     active = true;
 }
@@ -56,6 +60,7 @@ int profile_collect(sisic_ctx* ctx) {
         float ms = 0.f;
         SISIC_HIP(hipEventElapsedTime(&ms, ev.start, ev.stop));
         ctx->prof[ev.kind].ms += ms;
+        if (ev.kind2 >= 0) ctx->prof[ev.kind2].ms += ms;
         ctx->event_pool.push_back(ev.start);
         ctx->event_pool.push_back(ev.stop);
     }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -41,7 +42,9 @@ void set_error(const char* fmt, ...);
         if (_rc != SISIC_OK) return _rc; \
     } while (0)
 
-enum ProfileKind { PK_CONV3 = 0, PK_CONV1 = 1, PK_GN = 2, PK_ATTN = 3, PK_DDPM = 4, PK_OTHER = 5, PK_COUNT = 6 };
+// PK_WINO_MAIN: the dominant kernel on its own -- conv_winograd_kernel<1,8,8,PRO,16,false> launches are credited to
+// PK_CONV3 (the class) AND to this slot (same event pair)
+enum ProfileKind { PK_CONV3 = 0, PK_CONV1 = 1, PK_GN = 2, PK_ATTN = 3, PK_DDPM = 4, PK_OTHER = 5, PK_WINO_MAIN = 6, PK_COUNT = 7 };
 
 struct ProfileSlot {
     double ms = 0, bytes = 0, flops = 0, flops_exec = 0;   // flops: algorithmic (2*MAC of the direct form); flops_exec: issued to the matrix pipe
@@ -51,6 +54,7 @@ struct ProfileSlot {
 struct PendingEvent {
     hipEvent_t start, stop;
     int kind;
+    int kind2;      // second slot credited with the same launch, or -1
 };
 
 }  // namespace sisic
@@ -77,11 +81,22 @@ struct ProfileScope {
     hipStream_t stream;
     PendingEvent ev{};
     bool active = false;
-    ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops, double flops_exec = -1.0);
+    ProfileScope(sisic_ctx* c, hipStream_t s, int kind, double bytes, double flops, double flops_exec = -1.0, int kind2 = -1);
     ~ProfileScope();
 };
 
 int profile_collect(sisic_ctx* ctx);
+
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute belongs to the (kernel, device) pair, and several
+// devices and threads may use one process (sisic_create(device_id)), so every template instance keeps one bit per device
+// in an atomic mask; setting the attribute twice from two racing threads is harmless (same value).
+inline int ensure_dynamic_lds(sisic_ctx* ctx, const void* kern, int bytes, std::atomic<uint64_t>& done) {
+    const uint64_t bit = uint64_t(1) << (ctx->device & 63);
+    if (done.load(std::memory_order_acquire) & bit) return SISIC_OK;
+    SISIC_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return SISIC_OK;
+}
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -455,12 +455,8 @@ static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
         }
     }
     auto kern = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC, OCC, KSP>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)G::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_opt_in{0};     // one bit per device (common.h)
+    SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_opt_in));
     hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(G::NTHR), G::LDS_BYTES, s, p);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
@@ -487,11 +483,11 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s, int* slots_query);
 
 // Winograd F(2x2,3x3) is taken for 3x3 stride-1 convolutions with transformed filters at hand: when forced by
-// tile_cfg 60..71 / 90, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
+// tile_cfg 60..67 / 90, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
 // there are 32-bit).  Returns the tile configuration, 0 = not Winograd.
 static int winograd_cfg(const sisic_conv_args& a) {
     if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4) || a.upsample == 2) return 0;
-    if ((a.tile_cfg >= 60 && a.tile_cfg <= 71) || a.tile_cfg == 90) return a.tile_cfg;
+    if ((a.tile_cfg >= 60 && a.tile_cfg <= 67) || a.tile_cfg == 90) return a.tile_cfg;
     if (a.tile_cfg != 0) return 0;
     const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
     const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
@@ -510,10 +506,9 @@ static bool winograd_selected(const sisic_conv_args& a) { return winograd_cfg(a)
 // GroupNorm partials (sisic_conv_args.stats_out): the Winograd kernels' output transform leaves one slot per
 // workgroup tile of an image (16x16 outputs, or 8x8 for the four-image tilings; the K-split form one per image from
 // its reduction); the direct MFMA kernel one per pixel tile and pixel-wave (the dispatch below is asked which tiling
-// it would launch).  The third Winograd form and the vector-ALU small-Cout kernel do not produce them.
+// it would launch).  The vector-ALU small-Cout kernel does not produce them.
 int conv_stats_slots(const sisic_conv_args& a) {
     if (const int cfg = winograd_cfg(a)) {
-        if (cfg == 70 || cfg == 71) return 0;
         if (cfg == 90) return 1;
         const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
         const int edge = (cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 8 : 16;
@@ -568,7 +563,8 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     // of them for nearest-2x inputs (conv_winograd.hip, upsample form)
     const bool wino_ups9 = use_wino && a.upsample && !a.gn_scale && winograd_cfg(a) == 66;
     ProfileScope prof(slots_query ? nullptr : ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops,
-                      use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops);
+                      use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops,
+                      (use_wino && !wino_ups9 && winograd_cfg(a) == 66) ? PK_WINO_MAIN : -1);
 
     if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50)) {
         if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)
@@ -580,7 +576,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         SISIC_REQUIRE(!slots_query, "conv2d: internal: slot query on the Winograd path");
         return launch_conv_winograd(ctx, a, a.w_winograd, winograd_cfg(a), s);
     }
-    SISIC_REQUIRE((cfg < 60 || cfg > 71) && cfg != 90, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
+    SISIC_REQUIRE((cfg < 60 || cfg > 67) && cfg != 90, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 2>(ctx, p, s);   // 2-channel chunks: 4 spill 256 B/lane (13 weight float4 + 15 halo elements per thread)

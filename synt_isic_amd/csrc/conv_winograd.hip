@@ -746,7 +746,7 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int Cout, int 
 }
 
 int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s) {
-    const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout);     // 16: the third form stages 16 channels at a time
+    const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout);
     const size_t total = (size_t)cin_pad * cout_pad;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, cin_pad, cout_pad, packed);
@@ -755,8 +755,6 @@ int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* p
 }
 
 int64_t winograd_packed_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * conv_cout_pad(Cout); }
-
-#include "conv_winograd3.inc"
 
 // K-split reduction: out = sum_k part[k] + bias + per-sample channel bias + residual (+ReLU), and the GroupNorm partials
 // of the result.  One wave per (image, channel) plane of HW <= 256 pixels; the plane is the only statistics slot.
@@ -827,12 +825,8 @@ static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d(winograd): grid too large");
     p.nwg = (int)nwg;
     auto kern = conv_winograd_kernel<NIMG, TY, TX, PRO, NW, UPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)G::LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_opt_in{0};     // one bit per device (common.h)
+    SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_opt_in));
     hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(G::THREADS), G::LDS_BYTES, s, p);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
@@ -853,7 +847,6 @@ static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
 // tile_cfg 60: 1 image x 8x8 tiles (16x16 output pixels), 8 waves;  61: 4 images x 4x4 tiles (8x8 outputs each), 8 waves;
 //          62 / 63: the same two tilings with 16 waves (one transform position per wave, 4 waves per SIMD)
 //          64..67 = 60..63 with the MFMA-first / stage-first phase stagger between SIMD partner waves
-//          70 / 71: third form (conv_winograd3.inc): per-wave transform position, operands built in registers
 //          90: tiling 67 with the input channels split over four workgroups per tile + splitk_reduce_kernel -- for the
 //              8x8 level, where 64 tiles x 64 channels per workgroup leave 3/4 of the CUs without work
 int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s) {
@@ -868,7 +861,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu;
     p.out = a.out;
     p.stats = a.stats_out;
-    SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67 || cfg == 71 || cfg == 90) ? 4 : 1) < 4294967296.0,
+    SISIC_REQUIRE(4.0 * std::max(a.c0, a.c1) * a.Hin * a.Win * ((cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67 || cfg == 90) ? 4 : 1) < 4294967296.0,
                   "conv2d(winograd): per-thread load offsets are 32-bit; this tensor needs the direct kernel");
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
@@ -901,8 +894,6 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         return SISIC_OK;
     }
     switch (cfg) {
-        case 70: return launch_wino3_pro<1, 8, 8>(ctx, p, s);
-        case 71: return launch_wino3_pro<4, 4, 4>(ctx, p, s);
         case 64: return launch_wino_pro<1, 8, 8, 8>(ctx, p, s);
         case 65: return launch_wino_pro<4, 4, 4, 8>(ctx, p, s);
         case 66: return launch_wino_pro<1, 8, 8, 16>(ctx, p, s);

@@ -55,6 +55,7 @@ struct sisic_resnet {
     float* d_fc_b = nullptr;
     std::vector<float*> owned;
     std::vector<RBlock> pool;
+    int ws_B = 0, ws_H = 0, ws_W = 0;       // shape the pooled blocks were sized for (see workspace_for)
     bool loaded = false;
 
     int add(const std::string& n, int64_t numel) {
@@ -171,6 +172,19 @@ void pool_put(sisic_resnet* r, float* p) {
         if (b.p == p) { b.free_ = true; return; }
 }
 
+// The pool matches blocks by exact size, so every distinct (batch, resolution) would leave its own full set of
+// activation buffers behind (the stem output alone is B*64*112*112*4 bytes).  Like the UNet's check_shape, the pool is
+// therefore emptied whenever the input shape changes: resident workspace = what the current shape needs, whatever the
+// history of batch sizes (trajectory lengths, last chunks of Integrated Gradients, ...) has been.
+int workspace_for(sisic_resnet* r, int B, int H, int W) {
+    if (r->ws_B == B && r->ws_H == H && r->ws_W == W) return SISIC_OK;
+    SISIC_HIP(hipDeviceSynchronize());       // earlier launches may still use the blocks
+    for (auto& b : r->pool) (void)hipFree(b.p);
+    r->pool.clear();
+    r->ws_B = B; r->ws_H = H; r->ws_W = W;
+    return SISIC_OK;
+}
+
 int run_conv(sisic_resnet* r, const FoldedConv& c, const float* in, int B, int H, int W, const float* residual, bool relu,
              float* out, hipStream_t s) {
     sisic_conv_args a{};
@@ -205,6 +219,12 @@ int sisic_resnet_destroy(sisic_resnet* r) {
     for (auto& b : r->pool) (void)hipFree(b.p);
     delete r;
     return SISIC_OK;
+}
+
+int64_t sisic_resnet_workspace_bytes(const sisic_resnet* r) {
+    int64_t n = 0;
+    if (r) for (const auto& b : r->pool) n += (int64_t)b.bytes;
+    return n;
 }
 
 int sisic_resnet_num_tensors(const sisic_resnet* r) { return r ? (int)r->names.size() : 0; }
@@ -259,6 +279,7 @@ int sisic_resnet_forward(sisic_resnet* r, const float* x, float* logits, int B, 
         return SISIC_ESTATE;
     }
     SISIC_HIP(hipSetDevice(r->ctx->device));
+    SISIC_TRY(workspace_for(r, B, H, W));
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::vector<float*> live;
     auto get = [&](size_t floats, float** p) {
@@ -336,6 +357,7 @@ int sisic_resnet_input_gradient(sisic_resnet* r, const float* x, int B, int H, i
         return SISIC_ESTATE;
     }
     SISIC_HIP(hipSetDevice(r->ctx->device));
+    SISIC_TRY(workspace_for(r, B, H, W));
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::vector<float*> live;
     auto get = [&](size_t floats, float** p) {
@@ -472,6 +494,7 @@ int sisic_resnet_gradcam(sisic_resnet* r, const float* x, int B, int H, int W, i
         return SISIC_ESTATE;
     }
     SISIC_HIP(hipSetDevice(r->ctx->device));
+    SISIC_TRY(workspace_for(r, B, H, W));
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::vector<float*> live;
     auto get = [&](size_t floats, float** p) {

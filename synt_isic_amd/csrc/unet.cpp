@@ -650,6 +650,12 @@ int sisic_unet_destroy(sisic_unet* u) {
     return SISIC_OK;
 }
 
+int64_t sisic_unet_workspace_bytes(const sisic_unet* u) {
+    int64_t n = 0;
+    if (u) for (const auto& b : u->pool) n += (int64_t)b.bytes;
+    return n;
+}
+
 int sisic_unet_num_tensors(const sisic_unet* u) { return u ? (int)u->names.size() : 0; }
 
 const char* sisic_unet_tensor_name(const sisic_unet* u, int i) {

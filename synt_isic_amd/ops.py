@@ -163,7 +163,8 @@ def denorm_u8(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-_KINDS = {"conv3x3": 0, "conv1x1": 1, "groupnorm": 2, "attention": 3, "ddpm_step": 4, "other": 5}
+_KINDS = {"conv3x3": 0, "conv1x1": 1, "groupnorm": 2, "attention": 3, "ddpm_step": 4, "other": 5,
+          "conv3x3_winograd_main": 6}
 
 
 def profile_enable(device, on: bool) -> None:

@@ -162,6 +162,7 @@ class SampleResult:
     noise_hashes: List[str] = field(default_factory=list)
     timesteps: List[int] = field(default_factory=list)
     steps_done: int = 0
+    cancelled: bool = False                    # the stop flag ended the loop early: images/latents are NOT a result
 
 
 @torch.no_grad()
@@ -198,8 +199,11 @@ def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: t
                           C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != _lib.SISIC_ECANCEL:
         check(rc)
+    cancelled = rc == _lib.SISIC_ECANCEL
+    if cancelled:
+        out_u8.zero_()                         # never hand uninitialised pixels to a caller that ignores `cancelled`
     return SampleResult(images=out_u8, latents=x, trajectory=traj, timesteps=[int(t) for t in ts],
-                        steps_done=done.value)
+                        steps_done=done.value, cancelled=cancelled)
 
 
 def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch.Tensor, ns: NoiseStream,
@@ -241,8 +245,11 @@ def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch
             break
     if rc != _lib.SISIC_ECANCEL:
         check(rc)
+    cancelled = rc == _lib.SISIC_ECANCEL
+    if cancelled:
+        out_u8.zero_()
     return SampleResult(images=out_u8, latents=x, trajectory=traj, timesteps=[int(t) for t in ts],
-                        steps_done=done_total)
+                        steps_done=done_total, cancelled=cancelled)
 
 
 COLOR_BLEND = 0.35            # image_generator.py:532 "alpha"
@@ -311,7 +318,15 @@ class Sampler:
         return s
 
     def request_stop(self) -> None:
+        """Cooperative stop (``stop_generation``, image_generator.py:784-786): the running loop ends at the next step."""
         self.cancel.value = 1
+
+    def generate_images(self, class_name: str, seeds: Sequence[int], T: int, **kwargs) -> SampleResult:
+        """Start of a generation run in the reference's sense (``generate_images`` clears ``stop_requested`` before
+        its first image, image_generator.py:567): resets the stop flag, then samples ``seeds``.  A stop request that
+        arrives later ends this run only."""
+        self.cancel.value = 0
+        return self.generate_seeds(class_name, seeds, T, **kwargs)
 
     def generate_seeds(self, class_name: str, seeds: Sequence[int], T: int, size: Tuple[int, int] = (128, 128),
                        return_trajectory: bool = False) -> SampleResult:
@@ -351,7 +366,12 @@ class Sampler:
             seeds = [image_seed(seed, class_name, i) for i in range(count)]
         else:
             seeds = [(int(seed) + i) & 0x7FFFFFFF for i in range(count)]
-        res = self.generate_seeds(class_name, seeds, T, size, return_trajectory)
+        res = self.generate_images(class_name, seeds, T, size=size, return_trajectory=return_trajectory)
+        if res.cancelled:
+            # the reference returns False for a stopped image (image_generator.py:396-398); the tuple shape is kept, with
+            # no images, and the steps that did complete when a trajectory was asked for
+            traj = [res.trajectory[i] for i in range(res.steps_done)] if return_trajectory else None
+            return None, traj
         images = res.images.cpu().numpy()
         if postprocess:
             images = apply_color_statistics(images, self.color_statistics.get(class_name))

@@ -6,6 +6,8 @@ evaluation of the same op; the scheduler step, the de-normalisation and everythi
 import itertools
 
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -24,6 +26,9 @@ def _close(got: torch.Tensor, ref64: torch.Tensor, tol=2e-5, what=""):
     got = got.detach().cpu().double()
     bound = tol * max(1.0, ref64.abs().max().item())
     err = (got - ref64).abs().max().item()
+    if os.environ.get("SISIC_TEST_ERRLOG"):          # measured error / max(1,|ref|) of every comparison, for tolerance audits
+        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
+            f.write(f"{err / max(1.0, ref64.abs().max().item()):.3e}\t{tol:.1e}\t{what}\n")
     assert got.shape == ref64.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref64.shape)}"
     assert err <= bound, f"{what}: max abs err {err:.3e} > {bound:.3e}"
 
@@ -164,8 +169,7 @@ def _run_wino(x, w, cfg, **kw):
                                        (61, 8, 8, 8), (61, 5, 8, 8), (61, 3, 6, 10), (0, 2, 32, 32), (0, 2, 8, 8),
                                        (62, 2, 16, 16), (62, 2, 64, 64), (62, 3, 18, 10), (62, 2, 9, 23), (63, 8, 8, 8),
                                        (63, 5, 8, 8), (63, 3, 6, 10), (66, 2, 16, 16), (66, 3, 18, 10), (67, 5, 8, 8),
-                                       (70, 2, 16, 16), (70, 2, 64, 64), (70, 1, 32, 48), (70, 3, 18, 10), (70, 2, 9, 23),
-                                       (71, 8, 8, 8), (71, 5, 8, 8), (71, 3, 6, 10)])
+                                       ])
 def test_conv3x3_winograd(cfg, B, H, W):
     """Winograd F(2x2,3x3) on the MFMA pipe == the float64 convolution, plain and with every fused feature
     (cfg 60: 8x8 tiles of one image; 61: 4 images x 4x4 tiles; 0: auto dispatch with Winograd filters present)."""
@@ -185,7 +189,7 @@ def test_conv3x3_winograd(cfg, B, H, W):
 
 
 @pytest.mark.parametrize("cfg,H,W", [(60, 16, 16), (60, 8, 8), (60, 10, 14), (61, 4, 4), (62, 16, 16), (62, 10, 14),
-                                     (63, 4, 4), (70, 16, 16), (70, 10, 14), (71, 4, 4),
+                                     (63, 4, 4),
                                      # 66 / auto: the nine-position form for nearest-2x inputs
                                      (66, 16, 16), (66, 8, 8), (66, 10, 14), (66, 5, 9), (66, 32, 32), (0, 8, 8), (0, 20, 12)])
 def test_conv3x3_winograd_upsample(cfg, H, W):
@@ -247,7 +251,7 @@ def test_conv3x3_winograd_reference_layers_and_identity():
         xx = _rand(1, cin, r, r, seed=130 + i)
         ww = _rand(cout, cin, 3, 3, seed=140 + i, scale=(cin * 9) ** -0.5)
         bb = _rand(cout, seed=150 + i, scale=0.1)
-        for cfg in (60, 62, 70):
+        for cfg in (60, 62):
             _close(_run_wino(xx, ww, cfg, bias=bb), _conv_ref(xx, ww, bb), what=f"winograd{cfg} layer {cin}->{cout}@{r}")
     from synt_isic_amd import ops
     from synt_isic_amd._lib import SisicError

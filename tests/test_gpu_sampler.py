@@ -143,11 +143,28 @@ def test_cancel_flag_stops_the_loop(sampler):
     x_T, z = draw_noise([1], 49, (3, 32, 32))
     flag = ctypes.c_int(1)                                 # stop requested before the first step
     res = run_sampling_loop(sampler.models["NV"], sched, x_T.to(DEV), z.to(DEV), cancel_flag=flag)
-    assert res.steps_done == 0
+    assert res.steps_done == 0 and res.cancelled
     assert torch.equal(res.latents.cpu(), x_T)            # nothing was applied
+    assert int(res.images.max()) == 0                      # a cancelled run hands back zeros, never uninitialised pixels
     flag.value = 0
     res = run_sampling_loop(sampler.models["NV"], sched, x_T.to(DEV), z.to(DEV), cancel_flag=flag)
-    assert res.steps_done == 50
+    assert res.steps_done == 50 and not res.cancelled
+
+
+def test_stop_then_generate_then_generate(sampler):
+    """request_stop() -> generate -> generate (image_generator.py:567 clears stop_requested at the start of every
+    generate_images): a stale stop flag must not cancel later runs, and a cancelled run must not return pixels."""
+    base, _ = sampler.generate(5, "NV", 4, count=2, size=(32, 32))
+    sampler.request_stop()                                   # nothing is running: the flag is stale when generate starts
+    images, traj = sampler.generate(5, "NV", 4, count=2, size=(32, 32), return_trajectory=True)
+    assert images is not None and np.array_equal(images, base) and len(traj) == 4
+    again, _ = sampler.generate(5, "NV", 4, count=2, size=(32, 32))
+    assert np.array_equal(again, base)
+    # a stop that is pending inside the run (generate_seeds keeps the flag it is given): cancelled, zero-filled, flagged
+    sampler.cancel.value = 1
+    res = sampler.generate_seeds("NV", [5, 6], 4, (32, 32))
+    assert res.cancelled and res.steps_done == 0 and int(res.images.max()) == 0
+    sampler.cancel.value = 0
 
 
 def test_noise_shape_is_validated(sampler):
