@@ -145,6 +145,12 @@ int sisic_ddpm_step(sisic_ctx*, const float* eps, const float* x, const float* z
 /* De-normalise image_generator.py:441-447: [B,3,H,W] fp32 -> uint8 [B,H,W,3],
  * trunc(clamp((x+1)/2,0,1)*255).                                                   */
 int sisic_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, void* stream);
+/* The reference's three spellings of the same conversion, each in its own fp32 operation order:
+ *   form 0  image_generator.py:441-447       trunc(clamp((x+1)/2, 0, 1) * 255)            (= sisic_denorm_u8)
+ *   form 1  generate_test.py:94-97           trunc((clamp(x,-1,1) + 1) * 0.5 * 255)       (bit-equal to form 0)
+ *   form 2  diffusion_generator.py:231-232   trunc(clip((x+1) * 127.5, 0, 255))           (differs from form 0 where
+ *           the single multiplication rounds across an integer boundary)                                     */
+int sisic_denorm_u8_form(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, int form, void* stream);
 
 /* ---- UNet2DModel ---------------------------------------------------------------- */
 typedef struct sisic_unet_config {
@@ -205,6 +211,9 @@ int sisic_resnet_load(sisic_resnet*, int n, const char* const* names, const floa
  * normalised network input [B,3,H,W].                                                         */
 int sisic_resnet_forward(sisic_resnet*, const float* x, float* logits, int B, int H, int W, int preprocess,
                          void* stream);
+/* relu(bn1(conv1(preprocess(x)))): the stem activation [B,64,(S+1)/2,(S+1)/2] (S = 224 with preprocess=1) the max-pool
+ * routes are chosen from -- introspection for parity tests of the backward pass.                              */
+int sisic_resnet_stem(sisic_resnet*, const float* x, float* c1_out, int B, int H, int W, int preprocess, void* stream);
 /* d score / d x of the classifier for score = log(softmax(logits)[target] + 1e-8) (xai/XAI.py:443-459), x = the raw
  * input in [-1,1] with the pre-processing differentiated through (clamp, bilinear 224x224, normalise): the gradient
  * captum's IntegratedGradients(forward_func = get_per_class_score) and the plain-gradient fallback of

@@ -72,11 +72,18 @@ def _bn(sd, name, x):
                         sd[f"{name}.bias"], training=False, eps=BN_EPS)
 
 
-def resnet18_features(sd: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
-    """torchvision resnet18 in eval mode on an already normalised input -> logits."""
+def resnet18_features(sd: Dict[str, torch.Tensor], x: torch.Tensor,
+                      stem_override: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torchvision resnet18 in eval mode on an already normalised input -> logits.
+
+    stem_override (tests of a backward pass): VALUES of relu(bn1(conv1(x))) to use in place of the ones computed here,
+    while the gradient still flows through this graph (straight-through: y + (override - y).detach()).  The max-pool
+    that follows then takes the arg-maxima of the override, i.e. the routes of the implementation under test."""
     p = "model."
     x = F.conv2d(x, sd[p + "conv1.weight"], None, stride=2, padding=3)
     x = F.relu(_bn(sd, p + "bn1", x))
+    if stem_override is not None:
+        x = x + (stem_override.to(x.dtype) - x).detach()
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     in_ch = 64
     for l, width in enumerate((64, 128, 256, 512)):
@@ -111,13 +118,13 @@ def class_scores(sd, x: torch.Tensor, target_class: int):
     return p, torch.log(p + 1e-8)
 
 
-def score_input_gradient(sd, x: torch.Tensor, target_class: int):
+def score_input_gradient(sd, x: torch.Tensor, target_class: int, stem_override: Optional[torch.Tensor] = None):
     """d/dx of get_per_class_score = log(softmax(forward(x))[:, c] + 1e-8) by autograd over the restatement above
     (what ``_compute_gradient_attribution``, XAI.py:1086-1109, returns per sample, and what captum's
     IntegratedGradients differentiates at every Riemann point).  Returns (grad [B,3,H,W], logits [B,n])."""
     with torch.enable_grad():
         xg = x.detach().clone().requires_grad_(True)
-        logits = resnet18_features(sd, preprocess_for_classifier(xg))
+        logits = resnet18_features(sd, preprocess_for_classifier(xg), stem_override)
         score = torch.log(F.softmax(logits, dim=1)[:, target_class] + 1e-8)
         (grad,) = torch.autograd.grad(score.sum(), xg)
     return grad.detach(), logits.detach()

@@ -74,6 +74,20 @@ def denormalize_to_uint8(x: torch.Tensor) -> np.ndarray:
     return (img.cpu().numpy() * 255).astype(np.uint8)
 
 
+def denormalize_to_uint8_generate_test(x: torch.Tensor) -> np.ndarray:
+    """diffusion/generate_test.py:94-97, batched: clamp(-1,1), (x+1)*0.5, HWC, *255, astype(uint8)."""
+    image = x.clamp(-1, 1)
+    image = (image + 1) * 0.5
+    image = image.cpu().permute(0, 2, 3, 1).numpy()
+    return (image * 255).astype(np.uint8)
+
+
+def denormalize_to_uint8_diffusion_generator(x: torch.Tensor) -> np.ndarray:
+    """diffusion/diffusion_generator.py:231-232: numpy fp32 ((images + 1) * 127.5).clip(0, 255).astype(uint8)."""
+    images = x.permute(0, 2, 3, 1).cpu().numpy()
+    return ((images + 1) * 127.5).clip(0, 255).astype(np.uint8)
+
+
 def color_postprocess(image: np.ndarray, stats: Optional[dict]) -> np.ndarray:
     """image_generator.py:502-545 for one uint8 [H,W,3] image: per-channel mean/std matching towards the class
     statistics (``color_statistics.json`` entry ``{"rgb": {"mean": [...], "std": [...]}}``) with the scale clipped

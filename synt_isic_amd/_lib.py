@@ -75,6 +75,8 @@ SIGNATURES = {
     "sisic_ddpm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "sisic_denorm_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "sisic_denorm_u8_form": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p]),
     "sisic_unet_create": (C.c_int, [C.c_void_p, C.POINTER(UNetConfigC), C.POINTER(C.c_void_p)]),
     "sisic_unet_destroy": (C.c_int, [C.c_void_p]),
     "sisic_unet_num_tensors": (C.c_int, [C.c_void_p]),
@@ -92,6 +94,7 @@ SIGNATURES = {
     "sisic_resnet_load": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_int64_p]),
     "sisic_resnet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p]),
+    "sisic_resnet_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "sisic_resnet_input_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
     "sisic_resnet_gradcam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -210,6 +210,19 @@ class HipMelanomaClassifier:
         """p(c|x)   (XAI.py:467-471)."""
         return self._scores(x, target_class)[0]
 
+    @torch.no_grad()
+    def stem_activation(self, x: torch.Tensor) -> torch.Tensor:
+        """relu(bn1(conv1(preprocess(x)))) [B,64,112,112]: the tensor the stem's max-pool picks its arg-maxima from
+        (sisic_resnet_stem; used by the parity tests of the backward pass)."""
+        h = self.handle
+        x = x.to(self._device).detach().to(torch.float32).contiguous()
+        B, _, H, W = x.shape
+        out = torch.empty((B, 64, 112, 112), dtype=torch.float32, device=x.device)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        for lo, n in self._chunks(B, self.max_forward_batch):
+            check(_lib.load().sisic_resnet_stem(h, x[lo:].data_ptr(), out[lo:].data_ptr(), n, H, W, 1, stream))
+        return out
+
     def input_gradient(self, x: torch.Tensor, target_class: int):
         """(d get_per_class_score / d x, logits): the gradient captum's IntegratedGradients and the plain-gradient
         fallback of XAI.py:1039-1109 take, through the pre-processing, with no autograd graph -- the transposed

@@ -168,6 +168,11 @@ int sisic_denorm_u8(sisic_ctx* ctx, const float* x, uint8_t* out, int B, int C, 
     return launch_denorm_u8(ctx, x, out, B, C, H, W, static_cast<hipStream_t>(stream));
 }
 
+int sisic_denorm_u8_form(sisic_ctx* ctx, const float* x, uint8_t* out, int B, int C, int H, int W, int form, void* stream) {
+    SISIC_REQUIRE(ctx, "denorm_u8_form: null context");
+    return launch_denorm_u8(ctx, x, out, B, C, H, W, static_cast<hipStream_t>(stream), form);
+}
+
 int sisic_profile_enable(sisic_ctx* ctx, int on) {
     SISIC_REQUIRE(ctx, "profile_enable: null context");
     ctx->profiling = on != 0;

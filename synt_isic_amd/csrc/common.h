@@ -137,7 +137,7 @@ int launch_gn_stats(sisic_ctx*, const float* in0, int c0, const float* in1, int 
 int launch_attention(sisic_ctx*, const float* qkv, float* out, int B, int C, int N, int head_dim, hipStream_t s);
 int launch_ddpm_step(sisic_ctx*, const float* eps, const float* x, const float* z, float* out, int64_t n,
                      float sb, float sa, float c0, float c1, float sigma, float clip, hipStream_t s);
-int launch_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, hipStream_t s);
+int launch_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, hipStream_t s, int form = 0);
 // time embedding: sinusoid -> linear1 -> SiLU -> linear2 -> SiLU  (weights transposed [in][out])
 int launch_temb_mlp(sisic_ctx*, const float* t_vals, int B, const float* freqs, int n_freqs, const float* w1t,
                     const float* b1, const float* w2t, const float* b2, int hidden, float* temb_act, hipStream_t s);

@@ -72,6 +72,12 @@ int launch_ddpm_step(sisic_ctx* ctx, const float* eps, const float* x, const flo
 }
 
 // ---- de-normalise to uint8 HWC ---------------------------------------------------------------
+// FORM 0: image_generator.py:441-447     clamp((x + 1) / 2, 0, 1) * 255, truncated
+// FORM 1: generate_test.py:94-97          (clamp(x, -1, 1) + 1) * 0.5 * 255, truncated   (bit-equal to form 0)
+// FORM 2: diffusion_generator.py:231-232  clip((x + 1) * 127.5, 0, 255), truncated      (rounds differently: one
+//         multiplication by 127.5 instead of a halving and a multiplication by 255)
+// fp32 operation order of the respective torch / numpy expressions; this file is compiled without FMA contraction.
+template <int FORM>
 __global__ void __launch_bounds__(256)
 denorm_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int C, int HW, int64_t total) {
     // one thread per output byte: index = (b*HW + p)*C + c
@@ -81,18 +87,31 @@ denorm_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int C, 
         const int p = (int)(bp % HW);
         const int64_t b = bp / HW;
         float v = x[(b * C + c) * HW + p];
-        v = (v + 1.0f) / 2.0f;
-        v = fminf(fmaxf(v, 0.0f), 1.0f);
-        out[i] = (uint8_t)(int)(v * 255.0f);
+        if constexpr (FORM == 0) {
+            v = (v + 1.0f) / 2.0f;
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            v = v * 255.0f;
+        } else if constexpr (FORM == 1) {
+            v = fminf(fmaxf(v, -1.0f), 1.0f);
+            v = (v + 1.0f) * 0.5f;
+            v = v * 255.0f;
+        } else {
+            v = (v + 1.0f) * 127.5f;
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+        }
+        out[i] = (uint8_t)(int)v;
     }
 }
 
-int launch_denorm_u8(sisic_ctx* ctx, const float* x, uint8_t* out, int B, int C, int H, int W, hipStream_t s) {
+int launch_denorm_u8(sisic_ctx* ctx, const float* x, uint8_t* out, int B, int C, int H, int W, hipStream_t s, int form) {
     SISIC_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "denorm_u8: bad arguments");
+    SISIC_REQUIRE(form >= 0 && form <= 2, "denorm_u8: form %d (0 = image_generator, 1 = generate_test, 2 = diffusion_generator)", form);
     const int64_t total = (int64_t)B * C * H * W;
     ProfileScope prof(ctx, s, PK_OTHER, 5.0 * (double)total, 0.0);
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
-    hipLaunchKernelGGL(denorm_u8_kernel, dim3(blocks), dim3(256), 0, s, x, out, C, H * W, total);
+    if (form == 0) hipLaunchKernelGGL(denorm_u8_kernel<0>, dim3(blocks), dim3(256), 0, s, x, out, C, H * W, total);
+    else if (form == 1) hipLaunchKernelGGL(denorm_u8_kernel<1>, dim3(blocks), dim3(256), 0, s, x, out, C, H * W, total);
+    else hipLaunchKernelGGL(denorm_u8_kernel<2>, dim3(blocks), dim3(256), 0, s, x, out, C, H * W, total);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

@@ -344,6 +344,33 @@ int sisic_resnet_forward(sisic_resnet* r, const float* x, float* logits, int B, 
     return rc;
 }
 
+// The stem's activation relu(bn1(conv1(pre(x)))) alone: what the 3x3/2 max-pool chooses its arg-maxima from.  Parity tests
+// replay these routes in the CPU autograd pass (tests/test_gpu_classifier.py), so that input-gradient parity is a
+// max-abs statement instead of a statistical one.
+int sisic_resnet_stem(sisic_resnet* r, const float* x, float* c1_out, int B, int H, int W, int preprocess, void* stream) {
+    SISIC_REQUIRE(r && x && c1_out && B > 0 && H > 0 && W > 0, "resnet_stem: bad arguments");
+    if (!r->loaded) {
+        set_error("resnet_stem called before sisic_resnet_load");
+        return SISIC_ESTATE;
+    }
+    SISIC_HIP(hipSetDevice(r->ctx->device));
+    SISIC_TRY(workspace_for(r, B, H, W));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* cur = x;
+    int h = H, w = W;
+    float* pre = nullptr;
+    if (preprocess) {
+        const int S = 224;
+        SISIC_TRY(pool_get(r, (size_t)B * 3 * S * S, &pre));
+        const int rc = launch_preprocess(r->ctx, x, pre, B, H, W, S, S, s);
+        if (rc != SISIC_OK) { pool_put(r, pre); return rc; }
+        cur = pre; h = S; w = S;
+    }
+    const int rc = run_conv(r, r->stem, cur, B, h, w, nullptr, true, c1_out, s);
+    if (pre) pool_put(r, pre);
+    return rc;
+}
+
 // d score / d x for score = log(softmax(logits)[target] + 1e-8) (XAI.py:443-459), x the classifier's raw input in
 // [-1,1] (pre-processing included): the quantity captum's IntegratedGradients and the plain-gradient fallback of
 // XAI.py:1039-1109 differentiate.  Forward with the activations kept, then the transposed network (see

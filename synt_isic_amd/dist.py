@@ -51,10 +51,12 @@ def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[t
 
     Blocks may differ in length by one (``shard_range``); they are padded to the largest block for the
     collective and trimmed afterwards, so one gather serves ragged shards too."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         if local.shape[0] != n_total:
             raise ValueError("single-process gather expects the full batch")
         return local
+    # an initialised group of one rank still goes through the collective (RCCL on the GPU): the N>1 code path is the
+    # one that runs, whatever the world size
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_range(n_total, world, rank)
     if local.shape[0] != hi - lo:
@@ -77,7 +79,7 @@ def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[t
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

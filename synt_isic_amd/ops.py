@@ -155,11 +155,18 @@ def ddpm_step(eps: torch.Tensor, x: torch.Tensor, z: Optional[torch.Tensor], coe
     return out
 
 
-def denorm_u8(x: torch.Tensor) -> torch.Tensor:
+DENORM_FORMS = {"image_generator": 0, "generate_test": 1, "diffusion_generator": 2}
+
+
+def denorm_u8(x: torch.Tensor, form="image_generator") -> torch.Tensor:
+    """[B,C,H,W] fp32 -> uint8 [B,H,W,C] in the fp32 operation order of one of the reference's three call sites:
+    "image_generator" (image_generator.py:441-447), "generate_test" (generate_test.py:94-97, bit-equal to the first) or
+    "diffusion_generator" (diffusion_generator.py:231-232, `(x+1)*127.5` -- rounds differently)."""
     lib = _lib.load()
     B, Cc, H, W = x.shape
     out = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device)
-    check(lib.sisic_denorm_u8(context(x.device), _ptr(x, "x"), out.data_ptr(), B, Cc, H, W, _stream(x.device)))
+    f = DENORM_FORMS[form] if isinstance(form, str) else int(form)
+    check(lib.sisic_denorm_u8_form(context(x.device), _ptr(x, "x"), out.data_ptr(), B, Cc, H, W, f, _stream(x.device)))
     return out
 
 

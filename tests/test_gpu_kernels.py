@@ -555,6 +555,33 @@ def test_denorm_u8_bit_exact():
     assert np.array_equal(got, osampler.denormalize_to_uint8(x))
 
 
+def test_denorm_u8_three_reference_forms_bit_exact():
+    """The reference converts latents to uint8 in three places, each with its own fp32 operation order:
+    image_generator.py:441-447, generate_test.py:94-97 (bit-equal to the first) and diffusion_generator.py:231-232
+    (`(x+1)*127.5`, rounds differently).  Every form of the kernel equals its numpy/torch restatement bit for bit; the
+    inputs include every value that maps near an integer boundary of either scaling."""
+    from oracle import sampler as osampler
+    from synt_isic_amd import ops
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(4, 3, 64, 64, generator=g) * 0.7
+    # values at and around k/127.5 - 1 (the boundaries of form 2) and k/255*2 - 1 (forms 0/1), k = 0..255, +- a few ulps
+    k = torch.arange(0, 256, dtype=torch.float64)
+    edges = torch.cat([(k / 127.5 - 1).float(), (k / 255 * 2 - 1).float()])
+    ulps = torch.stack([torch.nextafter(edges, torch.full_like(edges, s)) for s in (-9.0, 9.0)] + [edges]).reshape(-1)
+    x.view(-1)[: ulps.numel()] = ulps
+    x[3, 2, 5, :6] = torch.tensor([-1.5, -1.0, 1.0, 3.0, float("inf"), -float("inf")])
+    xd = x.to(DEV)
+    a = ops.denorm_u8(xd, "image_generator").cpu().numpy()
+    b = ops.denorm_u8(xd, "generate_test").cpu().numpy()
+    c = ops.denorm_u8(xd, "diffusion_generator").cpu().numpy()
+    assert np.array_equal(a, osampler.denormalize_to_uint8(x))
+    assert np.array_equal(b, osampler.denormalize_to_uint8_generate_test(x))
+    assert np.array_equal(c, osampler.denormalize_to_uint8_diffusion_generator(x))
+    assert np.array_equal(a, b)                                   # the two spellings agree on every input
+    assert (a != c).any() and np.abs(a.astype(int) - c.astype(int)).max() <= 1   # the third rounds differently, by <= 1 LSB
+    assert np.array_equal(a, ops.denorm_u8(xd).cpu().numpy())    # default = image_generator.py's form
+
+
 def test_conv2d_auto_dispatch_fuzz():
     """sisic_conv2d with tile_cfg = 0 over 80 seeded random shapes and feature combinations against the float64
     convolution: whatever kernel the dispatch picks (direct, flat 1x1 with float4 staging, Winograd, nine-position

@@ -184,6 +184,52 @@ def test_oracle_classifier_matches_torch_modules():
     assert ref.shape == (2, 7) and torch.isfinite(ref).all()
 
 
+def test_oracle_classifier_matches_transformers_resnet():
+    """Independent third-party pin of oracle/resnet18.py (xai/XAI.py:389-394 builds torchvision's resnet18, which is not
+    installed here): the ResNet that ships with the installed `transformers` package, configured as ResNet-18
+    (layer_type="basic", depths 2-2-2-2, widths 64..512, 7x7/2 stem + 3x3/2 max-pool, fc -> 7), written by other people
+    from the same paper, gives the same logits for the same weights -- stem, stride placement (first 3x3 of a stage),
+    1x1/2 projection shortcuts, BatchNorm in eval mode, global average pool and the classifier head all agree."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import ResNetConfig, ResNetForImageClassification
+    from oracle import resnet18 as ores
+    sd = weights.synthetic_resnet18_state_dict()
+    cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512], depths=[2, 2, 2, 2],
+                       layer_type="basic", hidden_act="relu", downsample_in_first_stage=False, num_labels=7)
+    hf = ResNetForImageClassification(cfg).eval()
+
+    def bn_map(src, dst, out):
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            out[f"{dst}.normalization.{s}"] = sd[f"{src}.{s}"]
+
+    m = {"resnet.embedder.embedder.convolution.weight": sd["model.conv1.weight"]}
+    bn_map("model.bn1", "resnet.embedder.embedder", m)
+    for l in range(4):
+        for j in range(2):
+            src, dst = f"model.layer{l + 1}.{j}", f"resnet.encoder.stages.{l}.layers.{j}"
+            for c in (1, 2):
+                m[f"{dst}.layer.{c - 1}.convolution.weight"] = sd[f"{src}.conv{c}.weight"]
+                bn_map(f"{src}.bn{c}", f"{dst}.layer.{c - 1}", m)
+            if f"{src}.downsample.0.weight" in sd:
+                m[f"{dst}.shortcut.convolution.weight"] = sd[f"{src}.downsample.0.weight"]
+                bn_map(f"{src}.downsample.1", f"{dst}.shortcut", m)
+    m["classifier.1.weight"], m["classifier.1.bias"] = sd["model.fc.weight"], sd["model.fc.bias"]
+    res = hf.load_state_dict(m, strict=False)
+    assert not res.unexpected_keys and all(k.endswith("num_batches_tracked") for k in res.missing_keys)
+    assert sum(p.numel() for p in hf.parameters()) == ores.EXPECTED_NUM_PARAMS_7     # 11 180 103 (SURVEY Appendix C)
+    x = torch.randn(3, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        theirs = hf(pixel_values=x).logits
+        ours = ores.resnet18_features(sd, x)
+    assert torch.isfinite(ours).all() and ours.abs().max() > 1e-3
+    torch.testing.assert_close(ours, theirs, rtol=1e-5, atol=1e-5 * float(theirs.abs().max().clamp(min=1.0)))
+    # and through the reference's pre-processing at a non-native resolution (XAI.py:399-431)
+    x64 = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(6)).clamp(-1.5, 1.5)
+    with torch.no_grad():
+        torch.testing.assert_close(ores.classifier_forward(sd, x64),
+                                   hf(pixel_values=ores.preprocess_for_classifier(x64)).logits, rtol=1e-5, atol=2e-5)
+
+
 def test_product_does_not_import_oracle():
     import os
     import re
