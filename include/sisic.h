@@ -194,6 +194,61 @@ int sisic_sample(sisic_unet*, float* x, int B, int H, int W, int T, const int64_
                  const float* coef, float clip, const float* noise, float* traj, uint8_t* out_u8,
                  const volatile int* cancel, int* steps_done, void* stream);
 
+/* ---- training step (diffusion/train_diffusion.py:201-266) -----------------------------------
+ * fp32 throughout.  The reference wraps the forward in torch.cuda.amp.autocast() (fp16 matmuls/convolutions) and scales the
+ * loss with a GradScaler; here the GradScaler PROTOCOL is implemented (loss_scale multiplies d loss, the optimizer step
+ * unscales, checks for inf/nan and skips), the arithmetic stays fp32.
+ *
+ * train_begin allocates the gradient and Adam (m, v) arenas (zeroed, step count 0) and the filters of the backward-data
+ * convolutions; train_end frees them.  One tape at a time: train_forward records it, backward consumes it.           */
+int sisic_unet_train_begin(sisic_unet*);
+int sisic_unet_train_end(sisic_unet*);
+/* DDPMScheduler.add_noise (train_diffusion.py:217): out[b] = sqrt_alpha_prod[b] * x0[b] + sqrt_one_minus_alpha_prod[b] *
+ * noise[b]; the two coefficient rows are DEVICE arrays [B] (alphas_cumprod[t]**0.5 and (1 - alphas_cumprod[t])**0.5 as
+ * fp32, built by the caller), per_sample = C*H*W.  Two products and one sum in fp32, no FMA: bit-equal to torch.        */
+int sisic_add_noise(sisic_ctx*, const float* x0, const float* noise, const float* sqrt_alpha_prod,
+                    const float* sqrt_one_minus_alpha_prod, float* out, int B, int64_t per_sample, void* stream);
+/* noise_pred = model(noisy, timesteps).sample in training mode (train_diffusion.py:218): the inference kernels, every
+ * activation and GroupNorm statistic kept for the backward pass.  timesteps: host int64 [B], one per sample.          */
+int sisic_unet_train_forward(sisic_unet*, const float* sample, const int64_t* timesteps, float* out, int B, int H, int W,
+                             void* stream);
+/* F.mse_loss(pred, target) (train_diffusion.py:219): loss_dev[0] = mean((pred - target)^2) (NULL: kept internally),
+ * dpred = grad_scale * 2 (pred - target) / n (NULL: loss only).  Fixed-order reduction.                               */
+int sisic_mse_loss(sisic_unet*, const float* pred, const float* target, int64_t n, float grad_scale, float* loss_dev,
+                   float* dpred, void* stream);
+/* loss.backward() (train_diffusion.py:231): dout = d loss / d model output [B,C,H,W]; fills the gradient arena
+ * (overwrites: one backward per step, like zero_grad(set_to_none=True) + backward) and releases the tape.              */
+int sisic_unet_backward(sisic_unet*, const float* dout, void* stream);
+int sisic_unet_zero_grad(sisic_unet*, void* stream);
+/* scaler.step(optimizer) (train_diffusion.py:232-233) with torch.optim.Adam's update: gradients are multiplied by inv_scale,
+ * m/v/step advance, parameters move, and every packed form of the weights is rebuilt.  found_inf != NULL: the gradients are
+ * first checked for inf/nan (one synchronisation); *found_inf = 1 skips the update like GradScaler.step does.           */
+int sisic_unet_optimizer_step(sisic_unet*, float lr, float beta1, float beta2, float eps, float inv_scale, int* found_inf,
+                              void* stream);
+/* The whole loop body (train_diffusion.py:215-233) on one stream: add_noise, forward, MSE, backward, optimizer step.
+ * images / noise: dev [B,C,H,W]; timesteps and the two add_noise coefficient rows: HOST arrays [B].
+ * loss_out (host, may be NULL) receives the unscaled loss (one synchronisation).                                       */
+int sisic_unet_train_step(sisic_unet*, const float* images, const float* noise, const int64_t* timesteps,
+                          const float* sqrt_alpha_prod, const float* sqrt_one_minus_alpha_prod, int B, int H, int W, float lr,
+                          float beta1, float beta2, float eps, float loss_scale, float* loss_out, int* found_inf, void* stream);
+/* Copy one tensor of the state dict (index as in sisic_unet_tensor_name) to the host: what = 0 parameter, 1 gradient,
+ * 2 Adam first moment, 3 Adam second moment.  Synchronises the device.                                                  */
+int sisic_unet_read(sisic_unet*, int what, int index, float* host_out, int64_t numel);
+int64_t sisic_unet_train_steps(const sisic_unet*);
+
+/* Single-operator entry points of the backward pass (parity-test surface).
+ * dW of a convolution: arguments as sisic_conv_args (prologue and index maps of the FORWARD convolution), dy = gradient of
+ * its output, dw = OIHW [Cout, c0+c1, k, k].                                                                            */
+int sisic_conv2d_wgrad(sisic_ctx*, const sisic_conv_args* fwd_args, const float* dy, float* dw, void* stream);
+/* attention backward: dqkv [B,3C,N] from qkv, the forward output o [B,C,N] and its gradient dO.                         */
+int sisic_attention_bwd(sisic_ctx*, const float* qkv, const float* o, const float* dO, float* dqkv, int B, int C, int N,
+                        int head_dim, void* stream);
+/* GroupNorm(+SiLU) backward: a = act(GroupNorm(x)); given da, ADDS dx to dx_accum and writes dgamma, dbeta.
+ * scale/shift: outputs of sisic_groupnorm_stats for x.                                                                  */
+int sisic_groupnorm_bwd(sisic_ctx*, const float* da, const float* x, int B, int C, int HW, int groups, float eps,
+                        const float* gamma, const float* beta, int silu, float* dx_accum, float* dgamma, float* dbeta,
+                        void* stream);
+
 /* ---- ResNet18 classifier (xai/XAI.py:357-471, forward only) ---------------------------- */
 /* torchvision resnet18 with fc -> num_classes, eval mode (BatchNorm folded at load).  The state dict
  * uses the reference's key names, prefixed "model." (XAI.py:389), float tensors only: conv/fc weights

@@ -134,3 +134,16 @@ class DDPMSchedulerOracle:
 
     def all_coefficients(self) -> List[StepCoefficients]:
         return [self.coefficients(t) for t in self.timesteps]
+
+
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """Published ``DDPMScheduler.add_noise`` (called at diffusion/train_diffusion.py:217): per-sample
+        sqrt(abar_t) * x0 + sqrt(1 - abar_t) * noise, coefficients broadcast over the trailing dimensions."""
+        acp = self.alphas_cumprod.to(dtype=original_samples.dtype)
+        t = timesteps.to(torch.int64)
+        sqrt_alpha_prod = (acp[t] ** 0.5).flatten()
+        sqrt_one_minus = ((1 - acp[t]) ** 0.5).flatten()
+        while sqrt_alpha_prod.dim() < original_samples.dim():
+            sqrt_alpha_prod = sqrt_alpha_prod.unsqueeze(-1)
+            sqrt_one_minus = sqrt_one_minus.unsqueeze(-1)
+        return sqrt_alpha_prod * original_samples + sqrt_one_minus * noise

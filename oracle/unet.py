@@ -178,7 +178,7 @@ def attention_block(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor) -> tor
     split = lambda z: z.reshape(B, H * W, heads, HEAD_DIM).transpose(1, 2)   # [B, heads, N, d]
     q, k, v = split(q), split(k), split(v)
     scores = torch.matmul(q, k.transpose(-1, -2)) * (HEAD_DIM ** -0.5)
-    probs = torch.softmax(scores.float(), dim=-1)
+    probs = torch.softmax(scores if scores.dtype == torch.float64 else scores.float(), dim=-1)   # fp32 softmax (float64 only for rounding-free test references)
     o = torch.matmul(probs, v)                                      # [B, heads, N, d]
     o = o.transpose(1, 2).reshape(B, H * W, C)
     o = F.linear(o, sd[f"{p}.to_out.0.weight"], sd[f"{p}.to_out.0.bias"])

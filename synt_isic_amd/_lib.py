@@ -87,6 +87,28 @@ SIGNATURES = {
     "sisic_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int64_p, c_float_p,
                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.c_void_p]),
+    "sisic_unet_train_begin": (C.c_int, [C.c_void_p]),
+    "sisic_unet_train_end": (C.c_int, [C.c_void_p]),
+    "sisic_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_int64, C.c_void_p]),
+    "sisic_unet_train_forward": (C.c_int, [C.c_void_p, C.c_void_p, c_int64_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p]),
+    "sisic_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    "sisic_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sisic_unet_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sisic_unet_optimizer_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            C.POINTER(C.c_int), C.c_void_p]),
+    "sisic_unet_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int64_p, c_float_p, c_float_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_void_p]),
+    "sisic_unet_read": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, C.c_int64]),
+    "sisic_unet_train_steps": (C.c_int64, [C.c_void_p]),
+    "sisic_conv2d_wgrad": (C.c_int, [C.c_void_p, C.POINTER(ConvArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sisic_attention_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_void_p]),
+    "sisic_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sisic_resnet_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "sisic_resnet_destroy": (C.c_int, [C.c_void_p]),
     "sisic_resnet_num_tensors": (C.c_int, [C.c_void_p]),

@@ -125,22 +125,26 @@ int launch_add_relu(sisic_ctx*, const float* y, const float* identity, float* ou
 int launch_gradcam(sisic_ctx*, const float* y, const float* outp, const float* fc_w, const float* bias, float* cam, int B, int C,
                    int h, int w, int S, int target, hipStream_t s);
 int conv_stats_slots(const sisic_conv_args& a);
+// mean_rstd (optional, training): [B, groups, 2] = (mean, rstd) of every (sample, group)
 int launch_gn_finalize(sisic_ctx*, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
                        int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
-                       hipStream_t s);
+                       hipStream_t s, float* mean_rstd = nullptr);
 int launch_conv_winograd(sisic_ctx*, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s);
 int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s);
 int64_t winograd_packed_numel(int Cout, int Cin);
 int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float* packed, hipStream_t s);
 int launch_gn_stats(sisic_ctx*, const float* in0, int c0, const float* in1, int c1, int B, int HW, int groups,
-                    float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s);
+                    float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s,
+                    float* mean_rstd = nullptr);
 int launch_attention(sisic_ctx*, const float* qkv, float* out, int B, int C, int N, int head_dim, hipStream_t s);
 int launch_ddpm_step(sisic_ctx*, const float* eps, const float* x, const float* z, float* out, int64_t n,
                      float sb, float sa, float c0, float c1, float sigma, float clip, hipStream_t s);
 int launch_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, hipStream_t s, int form = 0);
 // time embedding: sinusoid -> linear1 -> SiLU -> linear2 -> SiLU  (weights transposed [in][out])
+// save_* (optional, training): the sinusoid [B, 2 n_freqs] and the two linear outputs before their SiLU [B, hidden]
 int launch_temb_mlp(sisic_ctx*, const float* t_vals, int B, const float* freqs, int n_freqs, const float* w1t,
-                    const float* b1, const float* w2t, const float* b2, int hidden, float* temb_act, hipStream_t s);
+                    const float* b1, const float* w2t, const float* b2, int hidden, float* temb_act, hipStream_t s,
+                    float* save_emb = nullptr, float* save_h1 = nullptr, float* save_t2 = nullptr);
 // out[b, r] = sum_k wt[k][r] * x[b][k] + bias[r]
 int launch_linear_t(sisic_ctx*, const float* x, int B, int K, const float* wt, const float* bias, int R,
                     float* out, hipStream_t s);

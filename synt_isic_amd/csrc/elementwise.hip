@@ -123,7 +123,8 @@ __device__ __forceinline__ float silu_acc(float v) { return v / (1.0f + expf(-v)
 __global__ void __launch_bounds__(256)
 temb_mlp_kernel(const float* __restrict__ t_vals, const float* __restrict__ freqs, int n_freqs,
                 const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w2t,
-                const float* __restrict__ b2, int hidden, float* __restrict__ temb_act) {
+                const float* __restrict__ b2, int hidden, float* __restrict__ temb_act, float* __restrict__ save_emb,
+                float* __restrict__ save_h1, float* __restrict__ save_t2) {
     __shared__ float e[256];
     __shared__ float h[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -132,27 +133,31 @@ temb_mlp_kernel(const float* __restrict__ t_vals, const float* __restrict__ freq
     for (int k = tid; k < nin; k += blockDim.x) {
         const float arg = t * freqs[k % n_freqs];
         e[k] = (k < n_freqs) ? cosf(arg) : sinf(arg);   // flip_sin_to_cos=True: cos half first
+        if (save_emb) save_emb[(size_t)b * nin + k] = e[k];
     }
     __syncthreads();
     for (int j = tid; j < hidden; j += blockDim.x) {
         float acc = 0.0f;
         for (int k = 0; k < nin; ++k) acc += w1t[(size_t)k * hidden + j] * e[k];
         h[j] = silu_acc(acc + b1[j]);
+        if (save_h1) save_h1[(size_t)b * hidden + j] = acc + b1[j];
     }
     __syncthreads();
     for (int j = tid; j < hidden; j += blockDim.x) {
         float acc = 0.0f;
         for (int k = 0; k < hidden; ++k) acc += w2t[(size_t)k * hidden + j] * h[k];
         temb_act[(size_t)b * hidden + j] = silu_acc(acc + b2[j]);
+        if (save_t2) save_t2[(size_t)b * hidden + j] = acc + b2[j];
     }
 }
 
 int launch_temb_mlp(sisic_ctx* ctx, const float* t_vals, int B, const float* freqs, int n_freqs, const float* w1t,
-                    const float* b1, const float* w2t, const float* b2, int hidden, float* temb_act, hipStream_t s) {
+                    const float* b1, const float* w2t, const float* b2, int hidden, float* temb_act, hipStream_t s,
+                    float* save_emb, float* save_h1, float* save_t2) {
     SISIC_REQUIRE(n_freqs > 0 && 2 * n_freqs <= 256 && hidden > 0 && hidden <= 1024, "temb_mlp: sizes unsupported");
     ProfileScope prof(ctx, s, PK_OTHER, 0.0, 0.0);
     hipLaunchKernelGGL(temb_mlp_kernel, dim3(B), dim3(256), 0, s, t_vals, freqs, n_freqs, w1t, b1, w2t, b2, hidden,
-                       temb_act);
+                       temb_act, save_emb, save_h1, save_t2);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

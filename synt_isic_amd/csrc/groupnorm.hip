@@ -39,7 +39,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 __global__ void __launch_bounds__(GN_THREADS)
 gn_stats_kernel(const float* __restrict__ in0, int c0, const float* __restrict__ in1, int c1, int HW, int groups,
                 float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                float* __restrict__ scale, float* __restrict__ shift, int aligned16) {
+                float* __restrict__ scale, float* __restrict__ shift, int aligned16, float* __restrict__ mean_rstd) {
     __shared__ float red[GN_THREADS / 64];
     const int C = c0 + c1;
     const int cpg = C / groups;
@@ -93,6 +93,10 @@ gn_stats_kernel(const float* __restrict__ in0, int c0, const float* __restrict__
     const float mean = K + m1;
     const float var = fmaxf(m2 - m1 * m1, 0.0f);
     const float rstd = 1.0f / sqrtf(var + eps);
+    if (mean_rstd && tid == 0) {
+        mean_rstd[2 * (size_t)blockIdx.x] = mean;
+        mean_rstd[2 * (size_t)blockIdx.x + 1] = rstd;
+    }
     if (tid < cpg) {
         const int c = g * cpg + tid;
         const float sc = gamma[c] * rstd;
@@ -102,7 +106,8 @@ gn_stats_kernel(const float* __restrict__ in0, int c0, const float* __restrict__
 }
 
 int launch_gn_stats(sisic_ctx* ctx, const float* in0, int c0, const float* in1, int c1, int B, int HW, int groups,
-                    float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s) {
+                    float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s,
+                    float* mean_rstd) {
     SISIC_REQUIRE(in0 && gamma && beta && scale && shift, "groupnorm_stats: null tensor");
     SISIC_REQUIRE((c1 == 0) == (in1 == nullptr), "groupnorm_stats: in1/c1 mismatch");
     const int C = c0 + c1;
@@ -111,7 +116,7 @@ int launch_gn_stats(sisic_ctx* ctx, const float* in0, int c0, const float* in1, 
     ProfileScope prof(ctx, s, PK_GN, 4.0 * B * C * HW + 8.0 * B * C, 0.0);
     const int aligned16 = ((reinterpret_cast<uintptr_t>(in0) | reinterpret_cast<uintptr_t>(in1)) & 15) == 0;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(GN_THREADS), 0, s, in0, c0, in1, c1, HW, groups, eps,
-                       gamma, beta, scale, shift, aligned16);
+                       gamma, beta, scale, shift, aligned16, mean_rstd);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
@@ -153,7 +158,7 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restric
                                                          const float4* __restrict__ st1, int c1, int slots1,
                                                          int groups, float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ scale,
-                                                         float* __restrict__ shift) {
+                                                         float* __restrict__ shift, float* __restrict__ mean_rstd) {
     const int C = c0 + c1, gs = C / groups;
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int lane = threadIdx.x;
@@ -205,6 +210,10 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restric
     const double var = fmax((m2 + between) / n, 0.0);
     const float rstd = 1.0f / sqrtf((float)var + eps);
     const float meanf = (float)mean;
+    if (mean_rstd && lane == 0) {
+        mean_rstd[2 * (size_t)blockIdx.x] = meanf;
+        mean_rstd[2 * (size_t)blockIdx.x + 1] = rstd;
+    }
     if (lane < gs) {
         const float sc = my_gamma * rstd;
         scale[(size_t)b * C + ca + lane] = sc;
@@ -220,7 +229,7 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restric
 
 int launch_gn_finalize(sisic_ctx* ctx, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
                        int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,
-                       hipStream_t s) {
+                       hipStream_t s, float* mean_rstd) {
     SISIC_REQUIRE(st0 && gamma && beta && scale && shift, "groupnorm_finalize: null tensor");
     SISIC_REQUIRE((c1 == 0) == (st1 == nullptr), "groupnorm_finalize: stats1/c1 mismatch");
     const int C = c0 + c1;
@@ -230,7 +239,7 @@ int launch_gn_finalize(sisic_ctx* ctx, const float* st0, int c0, int slots0, con
     ProfileScope prof(ctx, s, PK_GN, 16.0 * B * (c0 * (double)slots0 + c1 * (double)slots1) + 8.0 * B * C, 0.0);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, reinterpret_cast<const float4*>(st0), c0,
                        slots0, reinterpret_cast<const float4*>(st1), c1, slots1, groups, eps, gamma, beta, scale,
-                       shift);
+                       shift, mean_rstd);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

@@ -1,0 +1,697 @@
+// train_kernels.hip -- the kernels of the UNet training step that the sampling path does not have.
+//
+// Reference: diffusion/train_diffusion.py:201-266 -- per batch
+//     noise = randn_like(images); t = randint(0, 1000, (B,)); noisy = scheduler.add_noise(images, noise, t)       :215-217
+//     loss = mse_loss(model(noisy, t).sample, noise)                                                                :218-219
+//     scaler.scale(loss).backward(); scaler.step(Adam(lr=1e-4)); scaler.update()                                   :230-240
+// torch.autograd does the backward pass there.  Here it is explicit:
+//   * backward-DATA of every convolution is a sisic_conv2d launch with the transposed, tap-flipped filter (the forward
+//     kernels: Winograd F(2x2,3x3) / direct MFMA; stride 2 = zero-insertion form) -- nothing new in this file;
+//   * backward-WEIGHT is conv_wgrad_kernel below: an implicit GEMM  dW[co, (ci,tap)] = sum_pixels dy[co,p] * a[ci, p+tap]
+//     on v_mfma_f32_32x32x2_f32 with the PIXELS as the contraction dimension, the forward's GroupNorm+SiLU prologue
+//     recomputed while the input halo is staged (the normalised activation is never stored), K-split over pixel blocks
+//     with a fixed-order reduction (no atomics: bit-reproducible gradients);
+//   * GroupNorm(+SiLU) backward, attention backward (recomputing softmax per head, d = 8), the small linears of the time
+//     embedding, MSE, add_noise and Adam are HBM- or latency-bound vector kernels.
+#include "common.h"
+#include "train.h"
+
+namespace sisic {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum for 256-thread blocks, fixed order
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum_t(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ float sigmoid_acc(float v) { return 1.0f / (1.0f + expf(-v)); }
+// d silu(u) / du = s (1 + u (1 - s)),  s = sigmoid(u)
+__device__ __forceinline__ float silu_grad(float u) {
+    const float s = sigmoid_acc(u);
+    return s * (1.0f + u * (1.0f - s));
+}
+__device__ __forceinline__ float silu_fwd(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }   // as the forward kernels
+
+// ================================================================ convolution backward-weight ======================
+// Workgroup = 4 waves: 64 output channels x 64 input channels x KK taps of dW, summed over this workgroup's share of the
+// pixel blocks (TR x TC output pixels each).  Wave w owns the 32x32 block (co half w & 1, ci half w >> 1) for all taps:
+// KK accumulators of 16 registers.  Per pixel block: dy tile [64][P] and the input halo [64][IH*IW] (prologue applied,
+// zero padding after it, concat / nearest-2x index maps as in the forward) are staged in LDS; a k-step of the MFMA is two
+// neighbouring pixels; the A fragment (dy) is shared by the KK taps, the B fragment is the halo read at the tap's offset.
+struct WgradParams {
+    const float* in0; const float* in1; int c0, c1;
+    int B, Hin, Win, ups, Hc, Wc, Hout, Wout;
+    const float* gn_scale; const float* gn_shift; int gn_silu;
+    const float* dy; int Cout;
+    float* part;               // [ksplit][Cout][Cin][KK]
+    int ksplit, n_co_tiles, n_ci_tiles, tiles_x, tiles_y, nblocks, blocks_per_slice;
+};
+
+template <int KS, int STRIDE, int TR, int TC>
+struct WgradGeom {
+    static constexpr int KK = KS * KS;
+    static constexpr int PAD = KS / 2;
+    static constexpr int P = TR * TC;                       // output pixels per block
+    static constexpr int IH = (TR - 1) * STRIDE + KS, IW = (TC - 1) * STRIDE + KS;
+    static constexpr int HEL = IH * IW;
+    static constexpr int CHS = HEL | 1;                     // odd channel stride: the 32 lanes of a fragment read hit 32 banks
+    static constexpr int DYS = P + 1;
+    static constexpr size_t LDS_BYTES = (size_t)(64 * CHS + 64 * DYS) * sizeof(float);
+    static_assert(P % 2 == 0 && TC % 2 == 0, "two pixels of a row per MFMA k-step");
+};
+
+template <int KS, int STRIDE, int TR, int TC>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
+    using G = WgradGeom<KS, STRIDE, TR, TC>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const aL = smem;                     // [64 ci][CHS]
+    float* const dL = smem + 64 * G::CHS;       // [64 co][DYS]
+
+    int work = blockIdx.x;
+    const int co_t = work % p.n_co_tiles; work /= p.n_co_tiles;
+    const int ci_t = work % p.n_ci_tiles; work /= p.n_ci_tiles;
+    const int ks = work;
+    const int co0 = co_t * 64, ci0 = ci_t * 64;
+    const int Cin = p.c0 + p.c1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int mt = wave & 1, nt = wave >> 1;
+    const int HWin = p.Hin * p.Win, HWout = p.Hout * p.Wout;
+
+    f32x16 acc[G::KK];
+#pragma unroll
+    for (int t = 0; t < G::KK; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int blk_lo = ks * p.blocks_per_slice, blk_hi = min(p.nblocks, blk_lo + p.blocks_per_slice);
+    const float* a_base = aL + (nt * 32 + l31) * G::CHS + half * STRIDE;
+    const float* d_base = dL + (mt * 32 + l31) * G::DYS + half;
+
+    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+        int t = blk;
+        const int tx = t % p.tiles_x; t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        const int b = t / p.tiles_y;
+        const int oy0 = ty * TR, ox0 = tx * TC;
+        __syncthreads();                          // the previous block's fragments have been read
+        // ---- dy tile: 64 channels x P pixels, zero outside the image / past Cout
+        for (int i = tid; i < 64 * G::P; i += 256) {
+            const int co = i / G::P, px = i % G::P;
+            const int oy = oy0 + px / TC, ox = ox0 + px % TC;
+            const bool ok = (co0 + co) < p.Cout && oy < p.Hout && ox < p.Wout;
+            const size_t src = ((size_t)b * p.Cout + min(co0 + co, p.Cout - 1)) * HWout + (size_t)min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
+            const float v = p.dy[src];
+            dL[co * G::DYS + px] = ok ? v : 0.0f;
+        }
+        // ---- input halo: 64 channels x IH x IW with the forward's prologue, zero padding AFTER it
+        const int iy0 = oy0 * STRIDE - G::PAD, ix0 = ox0 * STRIDE - G::PAD;
+        for (int i = tid; i < 64 * G::HEL; i += 256) {
+            const int ci = i / G::HEL, r = i % G::HEL;
+            const int y = iy0 + r / G::IW, x = ix0 + r % G::IW;
+            const int c = ci0 + ci;
+            const bool ok = c < Cin && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
+            const int cc = min(c, Cin - 1);
+            const int ys = min(max(y, 0), p.Hc - 1) >> p.ups, xs = min(max(x, 0), p.Wc - 1) >> p.ups;
+            const float* plane = cc < p.c0 ? p.in0 + ((size_t)b * p.c0 + cc) * HWin
+                                           : p.in1 + ((size_t)b * p.c1 + (cc - p.c0)) * HWin;
+            float v = plane[ys * p.Win + xs];
+            if (p.gn_scale) {
+                v = v * p.gn_scale[(size_t)b * Cin + cc] + p.gn_shift[(size_t)b * Cin + cc];
+                if (p.gn_silu) v = silu_fwd(v);
+            }
+            aL[ci * G::CHS + r] = ok ? v : 0.0f;
+        }
+        __syncthreads();
+        // ---- P/2 k-steps x KK taps
+#pragma unroll 4
+        for (int kp = 0; kp < G::P / 2; ++kp) {
+            const int py = (2 * kp) / TC, pxx = (2 * kp) % TC;        // this lane's pixel is (py, pxx + half)
+            const float a = d_base[2 * kp];
+#pragma unroll
+            for (int t = 0; t < G::KK; ++t) {
+                const float bv = a_base[(py * STRIDE + t / KS) * G::IW + pxx * STRIDE + t % KS];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial dW of this slice: row = co, column (lane) = ci
+    float* const dst = p.part + (size_t)ks * p.Cout * Cin * G::KK;
+    const int ci = ci0 + nt * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + mt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (co < p.Cout && ci < Cin) {
+#pragma unroll
+            for (int t = 0; t < G::KK; ++t) dst[((size_t)co * Cin + ci) * G::KK + t] = acc[t][r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int ksplit, size_t n,
+                                                           float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = part[i];
+        for (int k = 1; k < ksplit; ++k) s += part[(size_t)k * n + i];      // fixed order
+        out[i] = s;
+    }
+}
+
+template <int KS, int STRIDE, int TR, int TC>
+static int launch_wgrad_cfg(sisic_ctx* ctx, WgradParams& p, hipStream_t s) {
+    using G = WgradGeom<KS, STRIDE, TR, TC>;
+    p.tiles_x = cdiv(p.Wout, TC);
+    p.tiles_y = cdiv(p.Hout, TR);
+    p.nblocks = p.B * p.tiles_x * p.tiles_y;
+    p.blocks_per_slice = cdiv(p.nblocks, p.ksplit);
+    p.ksplit = cdiv(p.nblocks, p.blocks_per_slice);       // no empty slices
+    auto kern = conv_wgrad_kernel<KS, STRIDE, TR, TC>;
+    static std::atomic<uint64_t> lds_opt_in{0};
+    SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_opt_in));
+    const int64_t nwg = (int64_t)p.n_co_tiles * p.n_ci_tiles * p.ksplit;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::LDS_BYTES, s, p);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+static int wgrad_ksplit(const WgradArgs& a, int Hout, int Wout) {
+    // enough workgroups for 256 CUs x 2: the weight tile count shrinks as the image grows and vice versa
+    const int tiles = cdiv(a.Cout, 64) * cdiv(a.c0 + a.c1, 64);
+    const int nblocks_min = a.B * cdiv(Hout, 8) * cdiv(Wout, 8);           // 64-pixel blocks
+    return std::max(1, std::min(nblocks_min, cdiv(768, tiles)));
+}
+
+static void wgrad_out_dims(const WgradArgs& a, int* Hout, int* Wout) {
+    const int Hc = a.Hin << (a.ups ? 1 : 0), Wc = a.Win << (a.ups ? 1 : 0), pad = a.ksize / 2;
+    *Hout = (Hc + 2 * pad - a.ksize) / a.stride + 1;
+    *Wout = (Wc + 2 * pad - a.ksize) / a.stride + 1;
+}
+
+size_t conv_wgrad_scratch_floats(const WgradArgs& a) {
+    int Hout, Wout;
+    wgrad_out_dims(a, &Hout, &Wout);
+    return (size_t)wgrad_ksplit(a, Hout, Wout) * a.Cout * (a.c0 + a.c1) * a.ksize * a.ksize;
+}
+
+int launch_conv_wgrad(sisic_ctx* ctx, const WgradArgs& a, float* part, size_t part_floats, hipStream_t s) {
+    SISIC_REQUIRE(a.in0 && a.dy && a.dw && part, "conv_wgrad: null tensor");
+    SISIC_REQUIRE((a.ksize == 1 || a.ksize == 3) && (a.stride == 1 || a.stride == 2), "conv_wgrad: ksize %d stride %d", a.ksize, a.stride);
+    SISIC_REQUIRE(!(a.ksize == 1 && (a.stride != 1 || a.ups)), "conv_wgrad: 1x1 is stride 1, no upsample");
+    SISIC_REQUIRE((a.c1 == 0) == (a.in1 == nullptr), "conv_wgrad: in1/c1 mismatch");
+    WgradParams p{};
+    p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1;
+    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.ups = a.ups ? 1 : 0;
+    p.Hc = a.Hin << p.ups; p.Wc = a.Win << p.ups;
+    wgrad_out_dims(a, &p.Hout, &p.Wout);
+    p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
+    p.dy = a.dy; p.Cout = a.Cout; p.part = part;
+    const int Cin = a.c0 + a.c1;
+    p.n_co_tiles = cdiv(a.Cout, 64); p.n_ci_tiles = cdiv(Cin, 64);
+    p.ksplit = wgrad_ksplit(a, p.Hout, p.Wout);
+    const size_t n = (size_t)a.Cout * Cin * a.ksize * a.ksize;
+    SISIC_REQUIRE((size_t)p.ksplit * n <= part_floats, "conv_wgrad: scratch too small");
+    const double flops = 2.0 * a.B * a.Cout * (double)p.Hout * p.Wout * Cin * a.ksize * a.ksize;
+    {
+        ProfileScope prof(ctx, s, PK_OTHER, 4.0 * a.B * ((double)Cin * a.Hin * a.Win + (double)a.Cout * p.Hout * p.Wout) + 4.0 * n, flops);
+        if (a.ksize == 1) {
+            // flat pixel rows: the image is one row of H*W pixels
+            p.Hin = 1; p.Win = a.Hin * a.Win; p.Hc = 1; p.Wc = p.Win; p.Hout = 1; p.Wout = p.Win;
+            SISIC_TRY((launch_wgrad_cfg<1, 1, 1, 64>(ctx, p, s)));
+        } else if (a.stride == 2) {
+            if (p.Wout > 8) SISIC_TRY((launch_wgrad_cfg<3, 2, 2, 16>(ctx, p, s)));
+            else SISIC_TRY((launch_wgrad_cfg<3, 2, 4, 8>(ctx, p, s)));
+        } else if (p.Wout > 16) {
+            SISIC_TRY((launch_wgrad_cfg<3, 1, 2, 32>(ctx, p, s)));
+        } else if (p.Wout > 8) {
+            SISIC_TRY((launch_wgrad_cfg<3, 1, 4, 16>(ctx, p, s)));
+        } else {
+            SISIC_TRY((launch_wgrad_cfg<3, 1, 8, 8>(ctx, p, s)));
+        }
+    }
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, p.ksplit, n, a.dw);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// W'[ci][co][KK-1-t] = W[co][ci][t]: the filter of the backward-data convolution
+__global__ void transpose_flip_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, float* __restrict__ wt) {
+    const size_t n = (size_t)Cout * Cin * KK;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % KK);
+        const size_t cc = i / KK;
+        const int ci = (int)(cc % Cin), co = (int)(cc / Cin);
+        wt[((size_t)ci * Cout + co) * KK + (KK - 1 - t)] = w[i];
+    }
+}
+
+int launch_transpose_flip(sisic_ctx*, const float* w, int Cout, int Cin, int KK, float* wt, hipStream_t s) {
+    const size_t n = (size_t)Cout * Cin * KK;
+    hipLaunchKernelGGL(transpose_flip_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, w, Cout,
+                       Cin, KK, wt);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// ================================================================ reductions over planes / rows =====================
+// out[plane] = sum of the plane's HW values; one wave per plane
+__global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict__ x, int planes, int HW, float* __restrict__ out) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (plane >= planes) return;
+    const float* src = x + (size_t)plane * HW;
+    float s = 0.0f;
+    for (int i = lane; i < HW; i += 64) s += src[i];
+    s = wave_sum_t(s);
+    if (lane == 0) out[plane] = s;
+}
+
+int launch_plane_sums(sisic_ctx*, const float* x, int planes, int HW, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(plane_sum_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, s, x, planes, HW, out);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// out[c] (+)= sum_r m[r * ld + c]
+__global__ void col_sum_kernel(const float* __restrict__ m, int rows, int cols, int ld, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; ++r) s += m[(size_t)r * ld + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+int launch_col_sums(sisic_ctx*, const float* m, int rows, int cols, int ld, float* out, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(col_sum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, m, rows, cols, ld, out, accumulate);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// dst[r * ld_dst + c] = src[r * cols + c]
+__global__ void copy_cols_kernel(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst, int ld_dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    dst[(size_t)(i / cols) * ld_dst + i % cols] = src[i];
+}
+
+int launch_copy_cols(sisic_ctx*, const float* src, int rows, int cols, float* dst, int ld_dst, hipStream_t s) {
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols, 256)), dim3(256), 0, s, src, rows, cols, dst, ld_dst);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// ================================================================ GroupNorm (+SiLU) backward ========================
+// Forward: u = x * scale[b,c] + shift[b,c] (= gamma xhat + beta), a = silu(u) or u.  Given da:
+//   du = da * silu'(u);  dgamma_c = sum_{b,hw} du xhat;  dbeta_c = sum_{b,hw} du
+//   dx = rstd * (gamma_c du - mean_g(gamma du) - xhat * mean_g(gamma du xhat))        (means over the group's cpg*HW elements)
+// Pass 1: per (b,c) plane the two sums A = sum du, Bx = sum du xhat.   Pass 2: dx, ADDED to the gradient of x.
+__global__ void __launch_bounds__(256)
+gn_bwd_reduce_kernel(const float* __restrict__ da, const float* __restrict__ in0, int c0, const float* __restrict__ in1, int c1,
+                     int HW, int groups, const float* __restrict__ scale, const float* __restrict__ shift,
+                     const float* __restrict__ mean_rstd, int silu, float* __restrict__ sumA, float* __restrict__ sumB) {
+    __shared__ float red[4];
+    const int C = c0 + c1, cpg = C / groups;
+    const int b = blockIdx.x / C, c = blockIdx.x % C, g = c / cpg;
+    const float* x = c < c0 ? in0 + ((size_t)b * c0 + c) * HW : in1 + ((size_t)b * c1 + (c - c0)) * HW;
+    const float* d = da + ((size_t)b * C + c) * HW;
+    const float sc = scale[(size_t)b * C + c], sh = shift[(size_t)b * C + c];
+    const float mean = mean_rstd[2 * ((size_t)b * groups + g)], rstd = mean_rstd[2 * ((size_t)b * groups + g) + 1];
+    float a = 0.0f, bx = 0.0f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float xv = x[i];
+        float du = d[i];
+        if (silu) du *= silu_grad(xv * sc + sh);
+        a += du;
+        bx += du * ((xv - mean) * rstd);
+    }
+    a = block_sum_256(a, red);
+    bx = block_sum_256(bx, red);
+    if (threadIdx.x == 0) {
+        sumA[(size_t)b * C + c] = a;
+        sumB[(size_t)b * C + c] = bx;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_kernel(const float* __restrict__ da, const float* __restrict__ in0, int c0, const float* __restrict__ in1, int c1,
+                    int HW, int groups, const float* __restrict__ scale, const float* __restrict__ shift,
+                    const float* __restrict__ mean_rstd, const float* __restrict__ gamma, int silu,
+                    const float* __restrict__ sumA, const float* __restrict__ sumB, float* __restrict__ g0,
+                    float* __restrict__ g1) {
+    const int C = c0 + c1, cpg = C / groups;
+    const int b = blockIdx.x / C, c = blockIdx.x % C, g = c / cpg;
+    const float* x = c < c0 ? in0 + ((size_t)b * c0 + c) * HW : in1 + ((size_t)b * c1 + (c - c0)) * HW;
+    float* dst = c < c0 ? g0 + ((size_t)b * c0 + c) * HW : g1 + ((size_t)b * c1 + (c - c0)) * HW;
+    const float* d = da + ((size_t)b * C + c) * HW;
+    const float sc = scale[(size_t)b * C + c], sh = shift[(size_t)b * C + c];
+    const float mean = mean_rstd[2 * ((size_t)b * groups + g)], rstd = mean_rstd[2 * ((size_t)b * groups + g) + 1];
+    float mA = 0.0f, mB = 0.0f;                 // every thread: the group's sums (cpg <= 16 values each), same order
+    for (int j = 0; j < cpg; ++j) {
+        const int cj = g * cpg + j;
+        mA += gamma[cj] * sumA[(size_t)b * C + cj];
+        mB += gamma[cj] * sumB[(size_t)b * C + cj];
+    }
+    const float inv_m = 1.0f / ((float)cpg * (float)HW);
+    mA *= inv_m; mB *= inv_m;
+    const float gm = gamma[c];
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float xv = x[i];
+        float du = d[i];
+        if (silu) du *= silu_grad(xv * sc + sh);
+        const float xh = (xv - mean) * rstd;
+        dst[i] += rstd * (gm * du - mA - xh * mB);
+    }
+}
+
+int launch_gn_bwd(sisic_ctx* ctx, const float* da, const float* in0, int c0, const float* in1, int c1, int B, int HW, int groups,
+                  const float* scale, const float* shift, const float* mean_rstd, const float* gamma, int silu,
+                  float* sums, float* g0, float* g1, float* dgamma, float* dbeta, hipStream_t s) {
+    const int C = c0 + c1;
+    SISIC_REQUIRE(da && in0 && scale && shift && mean_rstd && gamma && sums && g0 && (c1 == 0 || (in1 && g1)), "gn_bwd: null tensor");
+    float* sumA = sums;
+    float* sumB = sums + (size_t)B * C;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * C), dim3(256), 0, s, da, in0, c0, in1, c1, HW, groups, scale, shift,
+                       mean_rstd, silu, sumA, sumB);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, s, da, in0, c0, in1, c1, HW, groups, scale, shift, mean_rstd,
+                       gamma, silu, sumA, sumB, g0, g1);
+    SISIC_HIP(hipGetLastError());
+    SISIC_TRY(launch_col_sums(ctx, sumB, B, C, C, dgamma, 0, s));
+    SISIC_TRY(launch_col_sums(ctx, sumA, B, C, C, dbeta, 0, s));
+    return SISIC_OK;
+}
+
+// ================================================================ gradient routing ==================================
+// g0[b, c, :] += da[b, c, :] (c < c0);  g1[b, c - c0, :] += da[b, c, :]
+__global__ void accum_split_kernel(const float* __restrict__ da, int C, int HW, float* __restrict__ g0, int c0,
+                                   float* __restrict__ g1, int c1, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % HW);
+        const size_t bc = i / HW;
+        const int c = (int)(bc % C);
+        const size_t b = bc / C;
+        if (c < c0) g0[(b * c0 + c) * HW + px] += da[i];
+        else g1[(b * c1 + (c - c0)) * HW + px] += da[i];
+    }
+}
+
+int launch_accum_split(sisic_ctx*, const float* da, int B, int C, int HW, float* g0, int c0, float* g1, int c1, hipStream_t s) {
+    const size_t total = (size_t)B * C * HW;
+    hipLaunchKernelGGL(accum_split_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, da, C, HW,
+                       g0, c0, g1, c1, total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// nearest-2x upsample backward: g[b,c,y,x] += sum of the 2x2 block of da[b,c,2y..,2x..]
+__global__ void accum_pool2_kernel(const float* __restrict__ da, int H, int W, float* __restrict__ g, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const size_t plane = i / ((size_t)W * H);
+        const float* src = da + plane * 4 * H * W + (size_t)(2 * y) * 2 * W + 2 * x;
+        g[i] += (src[0] + src[1]) + (src[2 * W] + src[2 * W + 1]);
+    }
+}
+
+int launch_accum_pool2(sisic_ctx*, const float* da, int planes, int H, int W, float* g, hipStream_t s) {
+    const size_t total = (size_t)planes * H * W;
+    hipLaunchKernelGGL(accum_pool2_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, da, H, W, g,
+                       total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+int launch_add_inplace(sisic_ctx*, float* dst, const float* src, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, dst, src, n);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// ================================================================ attention backward ================================
+// One workgroup per (sample, head), d = 8.  q,k,v,dO of the head in LDS ([N][8] rows).  Softmax is recomputed:
+//   pass A (thread = query i):  m_i, l_i (online), D_i = dO_i . O_i,  dQ_i = scale * sum_j P_ij (dO_i . v_j - D_i) k_j
+//   pass B (thread = key j):    dV_j = sum_i P_ij dO_i,  dK_j = scale * sum_i P_ij (dO_i . v_j - D_i) q_i
+// P_ij = exp(scale q_i . k_j - m_i) / l_i.  No atomics: every output row has one owner.
+constexpr int ATB_THREADS = 256;
+
+__global__ void __launch_bounds__(ATB_THREADS)
+attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o, const float* __restrict__ dO,
+                     float* __restrict__ dqkv, int C, int N, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const qs = smem;                 // [N][8]
+    float* const ks_ = qs + (size_t)N * 8;
+    float* const vs = ks_ + (size_t)N * 8;
+    float* const gs = vs + (size_t)N * 8;   // dO
+    float* const ms = gs + (size_t)N * 8;   // [N] row max
+    float* const ls = ms + N;               // [N] 1 / row sum
+    float* const ds = ls + N;               // [N] D_i
+    const int heads = C / 8;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const size_t qoff = ((size_t)b * 3 * C + h * 8) * N, koff = qoff + (size_t)C * N, voff = koff + (size_t)C * N;
+    const size_t ooff = ((size_t)b * C + h * 8) * N;
+    for (int i = threadIdx.x; i < 8 * N; i += ATB_THREADS) {
+        const int d = i / N, n = i % N;                       // global reads run along n (contiguous)
+        qs[n * 8 + d] = qkv[qoff + (size_t)d * N + n];
+        ks_[n * 8 + d] = qkv[koff + (size_t)d * N + n];
+        vs[n * 8 + d] = qkv[voff + (size_t)d * N + n];
+        gs[n * 8 + d] = dO[ooff + (size_t)d * N + n];
+    }
+    __syncthreads();
+    // ---- pass A
+    for (int i = threadIdx.x; i < N; i += ATB_THREADS) {
+        float q[8], g[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { q[d] = qs[i * 8 + d] * scale; g[d] = gs[i * 8 + d]; }
+        float m = -INFINITY, l = 0.0f;
+        for (int j = 0; j < N; ++j) {
+            float sc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) sc += q[d] * ks_[j * 8 + d];
+            const float mn = fmaxf(m, sc);
+            l = l * expf(m - mn) + expf(sc - mn);
+            m = mn;
+        }
+        float D = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) D += g[d] * o[ooff + (size_t)d * N + i];
+        const float il = 1.0f / l;
+        float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < N; ++j) {
+            float sc = 0.0f, dp = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { sc += q[d] * ks_[j * 8 + d]; dp += g[d] * vs[j * 8 + d]; }
+            const float dsij = expf(sc - m) * il * (dp - D);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) dq[d] += dsij * ks_[j * 8 + d];
+        }
+        ms[i] = m; ls[i] = il; ds[i] = D;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dqkv[qoff + (size_t)d * N + i] = dq[d] * scale;
+    }
+    __syncthreads();
+    // ---- pass B
+    for (int j = threadIdx.x; j < N; j += ATB_THREADS) {
+        float k[8], v[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) { k[d] = ks_[j * 8 + d] * scale; v[d] = vs[j * 8 + d]; }
+        float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < N; ++i) {
+            float sc = 0.0f, dp = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { sc += qs[i * 8 + d] * k[d]; dp += gs[i * 8 + d] * v[d]; }
+            const float pij = expf(sc - ms[i]) * ls[i];
+            const float dsij = pij * (dp - ds[i]);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) { dv[d] += pij * gs[i * 8 + d]; dk[d] += dsij * qs[i * 8 + d]; }
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            dqkv[koff + (size_t)d * N + j] = dk[d] * scale;
+            dqkv[voff + (size_t)d * N + j] = dv[d];
+        }
+    }
+}
+
+int launch_attention_bwd(sisic_ctx* ctx, const float* qkv, const float* o, const float* dO, float* dqkv, int B, int C, int N,
+                         int head_dim, hipStream_t s) {
+    SISIC_REQUIRE(qkv && o && dO && dqkv && head_dim == 8 && C % 8 == 0, "attention_bwd: bad arguments");
+    const size_t lds = ((size_t)N * 32 + 3 * (size_t)N) * sizeof(float);
+    SISIC_REQUIRE(lds <= 160 * 1024, "attention_bwd: %d tokens do not fit the LDS (max 1170)", N);
+    static std::atomic<uint64_t> lds_opt_in{0};
+    SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(attention_bwd_kernel), 160 * 1024, lds_opt_in));
+    ProfileScope prof(ctx, s, PK_ATTN, 32.0 * B * C * N, 10.0 * B * C * double(N) * N);
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * (C / 8)), dim3(ATB_THREADS), lds, s, qkv, o, dO, dqkv, C, N, 0.35355339059327373f);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// ================================================================ small linears (time embedding) ====================
+// dW[r][k] = sum_b dy[b*ld + r] * x[b*K + k]
+__global__ void linear_wgrad_kernel(const float* __restrict__ dy, int ld, const float* __restrict__ x, int B, int R, int K,
+                                    float* __restrict__ dW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)R * K) return;
+    const int r = (int)(i / K), k = (int)(i % K);
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += dy[(size_t)b * ld + r] * x[(size_t)b * K + k];
+    dW[i] = s;
+}
+
+int launch_linear_wgrad(sisic_ctx*, const float* dy, int ld, const float* x, int B, int R, int K, float* dW, hipStream_t s) {
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((unsigned)(((size_t)R * K + 255) / 256)), dim3(256), 0, s, dy, ld, x, B, R, K, dW);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// dx[b][k] = sum_r dy[b*ld + r] * W[r][k];  W is [R][K] row-major, or (transposed) stored as [K][R]
+__global__ void linear_dgrad_kernel(const float* __restrict__ dy, int ld, const float* __restrict__ W, int R, int K,
+                                    float* __restrict__ dx, int transposed) {
+    const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const size_t sr = transposed ? 1 : (size_t)K, sk = transposed ? (size_t)R : 1;
+    float s = 0.0f;
+    for (int r = 0; r < R; ++r) s += dy[(size_t)b * ld + r] * W[r * sr + k * sk];
+    dx[(size_t)b * K + k] = s;
+}
+
+int launch_linear_dgrad(sisic_ctx*, const float* dy, int ld, const float* W, int B, int R, int K, float* dx, hipStream_t s,
+                        int w_is_transposed) {
+    hipLaunchKernelGGL(linear_dgrad_kernel, dim3(cdiv(K, 256), B), dim3(256), 0, s, dy, ld, W, R, K, dx, w_is_transposed);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// out = silu(pre) with the exact division (the time-embedding MLP's form, elementwise.hip)
+__global__ void silu_fwd_kernel(const float* __restrict__ pre, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pre[i] / (1.0f + expf(-pre[i]));
+}
+
+int launch_silu_fwd(sisic_ctx*, const float* pre, size_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(silu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pre, n, out);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// out = dy * silu'(pre)
+__global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dy[i] * silu_grad(pre[i]);
+}
+
+int launch_silu_bwd(sisic_ctx*, const float* dy, const float* pre, size_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, pre, n, out);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// ================================================================ loss, optimizer ===================================
+// loss = mean((pred - target)^2)  (F.mse_loss, train_diffusion.py:219);  dpred = grad_scale * 2 (pred - target) / n
+__global__ void __launch_bounds__(256) mse_partial_kernel(const float* __restrict__ pred, const float* __restrict__ target, size_t n,
+                                                          float gscale, float* __restrict__ dpred, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = pred[i] - target[i];
+        s += d * d;
+        if (dpred) dpred[i] = gscale * d;
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) mse_final_kernel(const float* __restrict__ part, int nparts, float inv_n, float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+
+int launch_mse(sisic_ctx*, const float* pred, const float* target, size_t n, float grad_scale, float* loss_dev, float* dpred,
+               float* part, int nparts, hipStream_t s) {
+    SISIC_REQUIRE(pred && target && loss_dev && part && n > 0 && nparts > 0, "mse: bad arguments");
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, (size_t)nparts);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, s, pred, target, n, grad_scale * 2.0f / (float)n, dpred, part);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, part, blocks, 1.0f / (float)n, loss_dev);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// flag |= 1 when any gradient is inf / nan (GradScaler's found_inf)
+__global__ void check_finite_kernel(const float* __restrict__ g, size_t n, int* __restrict__ flag) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        bad = bad || !isfinite(g[i]);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+int launch_check_finite(sisic_ctx*, const float* g, size_t n, int* flag, hipStream_t s) {
+    hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, s, g, n, flag);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// torch.optim.Adam (single-tensor form, no weight decay, no amsgrad), in its operation order:
+//   m = lerp(m, g, 1 - b1);  v = v * b2 + (1 - b2) g g;  denom = sqrt(v) / sqrt(bc2) + eps;  p = p - (lr / bc1) * m / denom
+// g is first multiplied by inv_scale (GradScaler.unscale_).
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float one_minus_b1, float b2, float one_minus_b2, float step_size, float bc2_sqrt, float eps,
+                            float inv_scale) {
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * inv_scale;
+        const float mi = m[i] + one_minus_b1 * (gi - m[i]);
+        const float vi = v[i] * b2 + one_minus_b2 * (gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+int launch_adam(sisic_ctx*, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                int64_t step, float inv_scale, hipStream_t s) {
+    const double bc1 = 1.0 - std::pow((double)b1, (double)step), bc2 = 1.0 - std::pow((double)b2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
+                       1.0f - b1, b2, 1.0f - b2, (float)((double)lr / bc1), (float)std::sqrt(bc2), eps, inv_scale);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// DDPMScheduler.add_noise (train_diffusion.py:217):  out[b] = a[b] * x0[b] + c[b] * noise[b]   (two products, one sum, fp32)
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ a,
+                                 const float* __restrict__ c, float* __restrict__ out, size_t per, size_t total) {
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / per;
+        const float t0 = a[b] * x0[i];
+        const float t1 = c[b] * noise[i];
+        out[i] = t0 + t1;
+    }
+}
+
+int launch_add_noise(sisic_ctx*, const float* x0, const float* noise, const float* a_dev, const float* c_dev, float* out, int B,
+                     size_t per, hipStream_t s) {
+    const size_t total = (size_t)B * per;
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, x0, noise,
+                       a_dev, c_dev, out, per, total);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+}  // namespace sisic

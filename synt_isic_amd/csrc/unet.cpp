@@ -18,123 +18,9 @@
 #include <map>
 #include <memory>
 
-#include "common.h"
+#include "unet_internal.h"
 
 using namespace sisic;
-
-namespace {
-
-struct ConvW {            // one convolution's parameters
-    int cout = 0, cin = 0, k = 0;
-    int w_idx = -1, b_idx = -1;   // indices into the state-dict tensor table (raw)
-    float* packed = nullptr;      // device, packed layout
-    float* wino = nullptr;        // device, Winograd-domain filters (3x3 stride-1 convolutions only)
-    bool strided = false;         // stride-2 downsampler: no Winograd form
-    const float* bias = nullptr;  // device
-};
-
-struct NormW {
-    int c = 0;
-    int w_idx = -1, b_idx = -1;
-    const float* gamma = nullptr;
-    const float* beta = nullptr;
-};
-
-struct ResnetW {
-    int cin = 0, cout = 0;
-    NormW norm1, norm2;
-    ConvW conv1, conv2, shortcut;   // shortcut.k == 0 when absent
-    int temb_w_idx = -1, temb_b_idx = -1;
-    int temb_off = 0;               // column offset in the fused time-embedding projection
-};
-
-struct AttnW {
-    int c = 0;
-    NormW norm;
-    int q_w = -1, q_b = -1, k_w = -1, k_b = -1, v_w = -1, v_b = -1, o_w = -1, o_b = -1;
-    float* qkv_packed = nullptr;    // [3C <- C] 1x1 conv
-    float* qkv_bias = nullptr;      // [3C]
-    ConvW out;                      // to_out.0 as 1x1 conv
-};
-
-struct Buf {
-    float* p = nullptr;
-    int C = 0, H = 0, W = 0;
-    int refs = 0;
-    float* stats = nullptr;   // GroupNorm partials written by the producing convolution (sisic_conv_args.stats_out)
-    int slots = 0;
-};
-
-struct PoolBlock {
-    float* p;
-    size_t bytes;
-    bool free_;
-};
-
-}  // namespace
-
-struct sisic_unet {
-    sisic_ctx* ctx = nullptr;
-    sisic_unet_config cfg{};
-    std::vector<float> freqs;
-
-    // expected state dict
-    std::vector<std::string> names;
-    std::vector<int64_t> numels;
-    std::vector<size_t> offsets;       // float offset of each raw tensor in `raw`
-    std::map<std::string, int> index;
-    float* raw = nullptr;              // device arena with the raw tensors
-    size_t raw_floats = 0;
-    std::vector<float*> owned;         // derived device buffers (packed weights, ...)
-    bool loaded = false;
-
-    // architecture
-    ConvW conv_in, conv_out;
-    NormW norm_out;
-    int temb_w1 = -1, temb_b1 = -1, temb_w2 = -1, temb_b2 = -1;
-    float* d_freqs = nullptr;
-    float* w1t = nullptr;  // [2*n_freqs][hidden]
-    float* w2t = nullptr;  // [hidden][hidden]
-    float* tproj_wt = nullptr;   // [hidden][tproj_R]
-    float* tproj_b = nullptr;    // [tproj_R]
-    int hidden = 0, tproj_R = 0;
-    std::vector<std::vector<ResnetW>> down_res, up_res;
-    std::vector<std::vector<AttnW>> down_attn, up_attn;
-    std::vector<ConvW> downsamplers, upsamplers;   // k==0 when absent
-    ResnetW mid_res[2];
-    AttnW mid_attn;
-    int max_c = 0;
-
-    // workspace
-    std::vector<PoolBlock> pool;
-    int ws_B = 0, ws_H = 0, ws_W = 0;
-    float* t_vals = nullptr;     // [B] or [T]
-    float* temb_act = nullptr;   // [B or T, hidden]
-    float* tproj = nullptr;      // [B or T, tproj_R]
-    float* gn_scale = nullptr;   // [B, max_c]
-    float* gn_shift = nullptr;
-    size_t t_vals_cap = 0, temb_act_cap = 0, tproj_cap = 0, gn_scale_cap = 0, gn_shift_cap = 0;
-    static constexpr int STAGE_SLOTS = 4;
-    float* stage_host = nullptr; // pinned upload ring
-    size_t stage_cap = 0;
-    uint64_t stage_next = 0;
-    hipEvent_t stage_ev[STAGE_SLOTS] = {};
-    bool stage_used[STAGE_SLOTS] = {};
-    bool use_winograd = true;
-    bool fuse_gn = true;            // GroupNorm statistics from convolution epilogues where the kernel offers them
-                                    // (SISIC_FUSED_GN=0 in the environment: always the stand-alone statistics pass)
-    // SISIC_WINOGRAD=0 in the environment keeps every 3x3 on the direct kernel
-    float* eps_buf = nullptr;    // sampling loop scratch [B,C,H,W]
-    size_t eps_floats = 0;
-
-    int add(const std::string& name, int64_t numel) {
-        index[name] = (int)names.size();
-        names.push_back(name);
-        numels.push_back(numel);
-        return (int)names.size() - 1;
-    }
-    const float* rawp(int idx) const { return raw + offsets[idx]; }
-};
 
 namespace {
 
@@ -237,6 +123,7 @@ int describe(sisic_unet* u) {
 
 // ------------------------------------------------------------------ derived weights
 int dev_alloc(sisic_unet* u, size_t floats, float** out) {
+    if (*out) return SISIC_OK;          // already there: prepare_* runs again after every optimizer step
     void* p = nullptr;
     SISIC_HIP(hipMalloc(&p, std::max<size_t>(floats, 4) * sizeof(float)));
     u->owned.push_back(static_cast<float*>(p));
@@ -244,14 +131,14 @@ int dev_alloc(sisic_unet* u, size_t floats, float** out) {
     return SISIC_OK;
 }
 
-int prepare_conv(sisic_unet* u, ConvW& c) {
+int prepare_conv(sisic_unet* u, ConvW& c, hipStream_t s) {
     if (c.k == 0) return SISIC_OK;
     SISIC_TRY(dev_alloc(u, (size_t)sisic_conv_packed_numel(c.cout, c.cin, c.k), &c.packed));
-    SISIC_TRY(launch_conv_pack(u->ctx, u->rawp(c.w_idx), c.cout, c.cin, c.k, c.packed, nullptr));
+    SISIC_TRY(launch_conv_pack(u->ctx, u->rawp(c.w_idx), c.cout, c.cin, c.k, c.packed, s));
     c.bias = u->rawp(c.b_idx);
     if (c.k == 3 && !c.strided && c.cout > 4) {
         SISIC_TRY(dev_alloc(u, (size_t)winograd_packed_numel(c.cout, c.cin), &c.wino));
-        SISIC_TRY(launch_winograd_pack(u->ctx, u->rawp(c.w_idx), c.cout, c.cin, c.wino, nullptr));
+        SISIC_TRY(launch_winograd_pack(u->ctx, u->rawp(c.w_idx), c.cout, c.cin, c.wino, s));
     }
     return SISIC_OK;
 }
@@ -259,63 +146,82 @@ void prepare_norm(sisic_unet* u, NormW& n) {
     n.gamma = u->rawp(n.w_idx);
     n.beta = u->rawp(n.b_idx);
 }
-int prepare_resnet(sisic_unet* u, ResnetW& r) {
+int prepare_resnet(sisic_unet* u, ResnetW& r, hipStream_t s) {
     prepare_norm(u, r.norm1);
     prepare_norm(u, r.norm2);
-    SISIC_TRY(prepare_conv(u, r.conv1));
-    SISIC_TRY(prepare_conv(u, r.conv2));
-    SISIC_TRY(prepare_conv(u, r.shortcut));
+    SISIC_TRY(prepare_conv(u, r.conv1, s));
+    SISIC_TRY(prepare_conv(u, r.conv2, s));
+    SISIC_TRY(prepare_conv(u, r.shortcut, s));
     // time_emb_proj.weight [cout, hidden] -> columns [temb_off, temb_off+cout) of tproj_wt [hidden][R]
-    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(r.temb_w_idx), r.cout, u->hidden, u->tproj_wt, u->tproj_R, r.temb_off, nullptr));
-    SISIC_HIP(hipMemcpy(u->tproj_b + r.temb_off, u->rawp(r.temb_b_idx), (size_t)r.cout * sizeof(float), hipMemcpyDeviceToDevice));
+    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(r.temb_w_idx), r.cout, u->hidden, u->tproj_wt, u->tproj_R, r.temb_off, s));
+    SISIC_HIP(hipMemcpyAsync(u->tproj_b + r.temb_off, u->rawp(r.temb_b_idx), (size_t)r.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
     return SISIC_OK;
 }
-int prepare_attn(sisic_unet* u, AttnW& a) {
+int prepare_attn(sisic_unet* u, AttnW& a, hipStream_t s) {
     prepare_norm(u, a.norm);
     const int c = a.c;
     // q,k,v as one [3C, C] 1x1 convolution
-    float* cat = nullptr;
-    SISIC_TRY(dev_alloc(u, (size_t)3 * c * c, &cat));
+    SISIC_TRY(dev_alloc(u, (size_t)3 * c * c, &a.qkv_cat));
+    float* cat = a.qkv_cat;
     const size_t wbytes = (size_t)c * c * sizeof(float);
-    SISIC_HIP(hipMemcpy(cat, u->rawp(a.q_w), wbytes, hipMemcpyDeviceToDevice));
-    SISIC_HIP(hipMemcpy(cat + (size_t)c * c, u->rawp(a.k_w), wbytes, hipMemcpyDeviceToDevice));
-    SISIC_HIP(hipMemcpy(cat + (size_t)2 * c * c, u->rawp(a.v_w), wbytes, hipMemcpyDeviceToDevice));
+    SISIC_HIP(hipMemcpyAsync(cat, u->rawp(a.q_w), wbytes, hipMemcpyDeviceToDevice, s));
+    SISIC_HIP(hipMemcpyAsync(cat + (size_t)c * c, u->rawp(a.k_w), wbytes, hipMemcpyDeviceToDevice, s));
+    SISIC_HIP(hipMemcpyAsync(cat + (size_t)2 * c * c, u->rawp(a.v_w), wbytes, hipMemcpyDeviceToDevice, s));
     SISIC_TRY(dev_alloc(u, (size_t)sisic_conv_packed_numel(3 * c, c, 1), &a.qkv_packed));
-    SISIC_TRY(launch_conv_pack(u->ctx, cat, 3 * c, c, 1, a.qkv_packed, nullptr));
+    SISIC_TRY(launch_conv_pack(u->ctx, cat, 3 * c, c, 1, a.qkv_packed, s));
     SISIC_TRY(dev_alloc(u, (size_t)3 * c, &a.qkv_bias));
-    SISIC_HIP(hipMemcpy(a.qkv_bias, u->rawp(a.q_b), c * sizeof(float), hipMemcpyDeviceToDevice));
-    SISIC_HIP(hipMemcpy(a.qkv_bias + c, u->rawp(a.k_b), c * sizeof(float), hipMemcpyDeviceToDevice));
-    SISIC_HIP(hipMemcpy(a.qkv_bias + 2 * c, u->rawp(a.v_b), c * sizeof(float), hipMemcpyDeviceToDevice));
-    SISIC_TRY(prepare_conv(u, a.out));
+    SISIC_HIP(hipMemcpyAsync(a.qkv_bias, u->rawp(a.q_b), c * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SISIC_HIP(hipMemcpyAsync(a.qkv_bias + c, u->rawp(a.k_b), c * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SISIC_HIP(hipMemcpyAsync(a.qkv_bias + 2 * c, u->rawp(a.v_b), c * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SISIC_TRY(prepare_conv(u, a.out, s));
     return SISIC_OK;
 }
 
-int prepare_all(sisic_unet* u) {
+int prepare_all(sisic_unet* u, hipStream_t s) {
     const int nin = 2 * u->cfg.n_freqs;
     SISIC_TRY(dev_alloc(u, u->cfg.n_freqs, &u->d_freqs));
-    SISIC_HIP(hipMemcpy(u->d_freqs, u->freqs.data(), u->freqs.size() * sizeof(float), hipMemcpyHostToDevice));
+    SISIC_HIP(hipMemcpyAsync(u->d_freqs, u->freqs.data(), u->freqs.size() * sizeof(float), hipMemcpyHostToDevice, s));
     SISIC_TRY(dev_alloc(u, (size_t)nin * u->hidden, &u->w1t));
     SISIC_TRY(dev_alloc(u, (size_t)u->hidden * u->hidden, &u->w2t));
     SISIC_TRY(dev_alloc(u, (size_t)u->hidden * u->tproj_R, &u->tproj_wt));
     SISIC_TRY(dev_alloc(u, (size_t)u->tproj_R, &u->tproj_b));
-    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(u->temb_w1), u->hidden, nin, u->w1t, u->hidden, 0, nullptr));
-    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(u->temb_w2), u->hidden, u->hidden, u->w2t, u->hidden, 0, nullptr));
-    SISIC_TRY(prepare_conv(u, u->conv_in));
-    SISIC_TRY(prepare_conv(u, u->conv_out));
+    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(u->temb_w1), u->hidden, nin, u->w1t, u->hidden, 0, s));
+    SISIC_TRY(launch_transpose2d(u->ctx, u->rawp(u->temb_w2), u->hidden, u->hidden, u->w2t, u->hidden, 0, s));
+    SISIC_TRY(prepare_conv(u, u->conv_in, s));
+    SISIC_TRY(prepare_conv(u, u->conv_out, s));
     prepare_norm(u, u->norm_out);
-    for (auto& blk : u->down_res) for (auto& r : blk) SISIC_TRY(prepare_resnet(u, r));
-    for (auto& blk : u->up_res) for (auto& r : blk) SISIC_TRY(prepare_resnet(u, r));
-    for (auto& r : u->mid_res) SISIC_TRY(prepare_resnet(u, r));
-    for (auto& blk : u->down_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a));
-    for (auto& blk : u->up_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a));
-    SISIC_TRY(prepare_attn(u, u->mid_attn));
+    for (auto& blk : u->down_res) for (auto& r : blk) SISIC_TRY(prepare_resnet(u, r, s));
+    for (auto& blk : u->up_res) for (auto& r : blk) SISIC_TRY(prepare_resnet(u, r, s));
+    for (auto& r : u->mid_res) SISIC_TRY(prepare_resnet(u, r, s));
+    for (auto& blk : u->down_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a, s));
+    for (auto& blk : u->up_attn) for (auto& a : blk) SISIC_TRY(prepare_attn(u, a, s));
+    SISIC_TRY(prepare_attn(u, u->mid_attn, s));
     for (auto& c : u->downsamplers) {
         c.strided = true;
-        SISIC_TRY(prepare_conv(u, c));
+        SISIC_TRY(prepare_conv(u, c, s));
     }
-    for (auto& c : u->upsamplers) SISIC_TRY(prepare_conv(u, c));
-    SISIC_HIP(hipDeviceSynchronize());
+    for (auto& c : u->upsamplers) SISIC_TRY(prepare_conv(u, c, s));
     return SISIC_OK;
+}
+
+// forget every derived buffer (they were freed): the next prepare_all allocates afresh
+void reset_conv(ConvW& c) { c.packed = c.wino = c.raw_t = c.packed_t = c.wino_t = nullptr; }
+void reset_attn(AttnW& a) {
+    a.qkv_cat = a.qkv_packed = a.qkv_bias = a.qkv_raw_t = a.qkv_packed_t = nullptr;
+    reset_conv(a.out);
+}
+void reset_resnet(ResnetW& r) { reset_conv(r.conv1); reset_conv(r.conv2); reset_conv(r.shortcut); }
+void reset_derived(sisic_unet* u) {
+    u->d_freqs = u->w1t = u->w2t = u->tproj_wt = u->tproj_b = nullptr;
+    reset_conv(u->conv_in); reset_conv(u->conv_out);
+    for (auto& blk : u->down_res) for (auto& r : blk) reset_resnet(r);
+    for (auto& blk : u->up_res) for (auto& r : blk) reset_resnet(r);
+    for (auto& r : u->mid_res) reset_resnet(r);
+    for (auto& blk : u->down_attn) for (auto& a : blk) reset_attn(a);
+    for (auto& blk : u->up_attn) for (auto& a : blk) reset_attn(a);
+    reset_attn(u->mid_attn);
+    for (auto& c : u->downsamplers) reset_conv(c);
+    for (auto& c : u->upsamplers) reset_conv(c);
 }
 
 // ------------------------------------------------------------------ workspace
@@ -398,6 +304,11 @@ struct Fwd {
     const float* tproj;   // [B or 1, tproj_R]
     int tproj_stride;     // tproj_R, or 0 when one row serves every sample
     std::vector<std::unique_ptr<Buf>> bufs;
+    TrainState* tr = nullptr;     // training mode: record every operation, keep every buffer, save each GroupNorm's statistics
+    float* gsc = nullptr;         // scale / shift the next convolution's prologue reads (the shared pair, or this op's own)
+    float* gsh = nullptr;
+    float* gmr = nullptr;         // training mode: (mean, rstd) of the same GroupNorm
+    const NormW* gnorm = nullptr;
 
     Buf* make(int C, int H, int W, int* rc) {
         auto b = std::make_unique<Buf>();
@@ -407,6 +318,7 @@ struct Fwd {
         return bufs.back().get();
     }
     void release(Buf* b) {
+        if (tr) return;           // the backward pass reads every activation
         if (b && --b->refs == 0 && b->p) {
             pool_put(u, b->p);
             b->p = nullptr;
@@ -415,23 +327,33 @@ struct Fwd {
     }
 
     int gn(const Buf* x, const Buf* skip, const NormW& n) {
+        gsc = u->gn_scale; gsh = u->gn_shift; gmr = nullptr; gnorm = &n;
+        if (tr) {                 // this GroupNorm's own scale / shift / (mean, rstd): the backward pass needs them
+            const int C = x->C + (skip ? skip->C : 0);
+            SISIC_TRY(pool_get(u, (size_t)B * C, &gsc));
+            SISIC_TRY(pool_get(u, (size_t)B * C, &gsh));
+            SISIC_TRY(pool_get(u, (size_t)B * u->cfg.norm_groups * 2, &gmr));
+            tr->grads_of_bufs.push_back(gsc); tr->grads_of_bufs.push_back(gsh); tr->grads_of_bufs.push_back(gmr);
+        }
         if (x->stats && (!skip || skip->stats))   // every producer left partials: no pass over the tensors
             return launch_gn_finalize(u->ctx, x->stats, x->C, x->slots, skip ? skip->stats : nullptr, skip ? skip->C : 0,
                                       skip ? skip->slots : 0, B, x->H * x->W, u->cfg.norm_groups, u->cfg.norm_eps,
-                                      n.gamma, n.beta, u->gn_scale, u->gn_shift, s);
+                                      n.gamma, n.beta, gsc, gsh, s, gmr);
         return launch_gn_stats(u->ctx, x->p, x->C, skip ? skip->p : nullptr, skip ? skip->C : 0, B, x->H * x->W,
-                               u->cfg.norm_groups, u->cfg.norm_eps, n.gamma, n.beta, u->gn_scale, u->gn_shift, s);
+                               u->cfg.norm_groups, u->cfg.norm_eps, n.gamma, n.beta, gsc, gsh, s, gmr);
     }
 
+    // xb / skipb / resb / outb: the buffers behind in0 / in1 / residual / out (training tape; nullptr = network input / output)
     int conv(const ConvW& c, const float* in0, int c0, const float* in1, int c1, int H, int W, int stride, int ups,
              bool gn_prologue, bool silu, const float* chan_bias, const float* residual, float* out,
-             Buf* normed_later = nullptr) {
+             Buf* normed_later = nullptr, Buf* xb = nullptr, Buf* skipb = nullptr, Buf* resb = nullptr, Buf* outb = nullptr,
+             const AttnW* qkv_of = nullptr) {
         sisic_conv_args a{};
         a.in0 = in0; a.c0 = c0; a.in1 = in1; a.c1 = c1;
         a.B = B; a.Hin = H; a.Win = W; a.upsample = ups; a.ksize = c.k; a.stride = stride;
         a.w_packed = c.packed; a.bias = c.bias; a.Cout = c.cout;
         a.w_winograd = (stride == 1 && u->use_winograd) ? c.wino : nullptr;
-        if (gn_prologue) { a.gn_scale = u->gn_scale; a.gn_shift = u->gn_shift; a.gn_silu = silu ? 1 : 0; }
+        if (gn_prologue) { a.gn_scale = gsc; a.gn_shift = gsh; a.gn_silu = silu ? 1 : 0; }
         a.chan_bias = chan_bias; a.chan_bias_stride = tproj_stride;
         a.residual = residual; a.out = out;
         if (normed_later && u->fuse_gn) {          // a GroupNorm reads this output: have the epilogue leave partials
@@ -441,6 +363,17 @@ struct Fwd {
                 normed_later->slots = slots;
                 a.stats_out = normed_later->stats;
             }
+        }
+        if (tr) {
+            TapeOp op;
+            op.kind = TapeOp::CONV;
+            op.w = c; op.qkv_of = qkv_of;
+            op.in0 = xb; op.in1 = skipb; op.in0_ptr = in0; op.in1_ptr = in1;
+            op.c0 = c0; op.c1 = c1; op.H = H; op.W = W; op.stride = stride; op.ups = ups;
+            if (gn_prologue) { op.norm = gnorm; op.gn_scale = gsc; op.gn_shift = gsh; op.gn_mr = gmr; op.silu = silu; }
+            op.temb_off = chan_bias ? (int)(chan_bias - tproj) : -1;
+            op.residual = resb; op.out = outb; op.out_ptr = out;
+            tr->tape.push_back(op);
         }
         return launch_conv2d(u->ctx, a, s);
     }
@@ -454,20 +387,23 @@ struct Fwd {
         SISIC_TRY(gn(x, skip, r.norm1));
         Buf* h = make(r.cout, H, W, &rc); SISIC_TRY(rc);
         SISIC_TRY(conv(r.conv1, x->p, x->C, skip ? skip->p : nullptr, c1, H, W, 1, 0, true, true,
-                       tproj + r.temb_off, nullptr, h->p, h));
+                       tproj + r.temb_off, nullptr, h->p, h, const_cast<Buf*>(x), const_cast<Buf*>(skip), nullptr, h));
         const float* residual = x->p;
+        Buf* resb = const_cast<Buf*>(x);
         Buf* sc = nullptr;
         if (r.shortcut.k) {
             sc = make(r.cout, H, W, &rc); SISIC_TRY(rc);
             SISIC_TRY(conv(r.shortcut, x->p, x->C, skip ? skip->p : nullptr, c1, H, W, 1, 0, false, false, nullptr,
-                           nullptr, sc->p));
+                           nullptr, sc->p, nullptr, const_cast<Buf*>(x), const_cast<Buf*>(skip), nullptr, sc));
             residual = sc->p;
+            resb = sc;
         } else {
             SISIC_REQUIRE(c1 == 0 && x->C == r.cout, "unet: identity shortcut with mismatched channels");
         }
         SISIC_TRY(gn(h, nullptr, r.norm2));
         Buf* o = make(r.cout, H, W, &rc); SISIC_TRY(rc);
-        SISIC_TRY(conv(r.conv2, h->p, r.cout, nullptr, 0, H, W, 1, 0, true, true, nullptr, residual, o->p, o));
+        SISIC_TRY(conv(r.conv2, h->p, r.cout, nullptr, 0, H, W, 1, 0, true, true, nullptr, residual, o->p, o, h, nullptr,
+                       resb, o));
         release(h);
         release(sc);
         *out = o;
@@ -481,12 +417,20 @@ struct Fwd {
         SISIC_TRY(gn(x, nullptr, a.norm));
         Buf* qkv = make(3 * C, H, W, &rc); SISIC_TRY(rc);
         ConvW cq; cq.cout = 3 * C; cq.cin = C; cq.k = 1; cq.packed = a.qkv_packed; cq.bias = a.qkv_bias;
-        SISIC_TRY(conv(cq, x->p, C, nullptr, 0, H, W, 1, 0, true, false, nullptr, nullptr, qkv->p));
+        SISIC_TRY(conv(cq, x->p, C, nullptr, 0, H, W, 1, 0, true, false, nullptr, nullptr, qkv->p, nullptr,
+                       const_cast<Buf*>(x), nullptr, nullptr, qkv, &a));
         Buf* o = make(C, H, W, &rc); SISIC_TRY(rc);
         SISIC_TRY(launch_attention(u->ctx, qkv->p, o->p, B, C, N, u->cfg.head_dim, s));
+        if (tr) {
+            TapeOp op;
+            op.kind = TapeOp::ATTN;
+            op.qkv = qkv; op.o = o; op.C = C; op.N = N;
+            tr->tape.push_back(op);
+        }
         release(qkv);
         Buf* y = make(C, H, W, &rc); SISIC_TRY(rc);
-        SISIC_TRY(conv(a.out, o->p, C, nullptr, 0, H, W, 1, 0, false, false, nullptr, x->p, y->p, y));
+        SISIC_TRY(conv(a.out, o->p, C, nullptr, 0, H, W, 1, 0, false, false, nullptr, x->p, y->p, y, o, nullptr,
+                       const_cast<Buf*>(x), y));
         release(o);
         *out = y;
         return SISIC_OK;
@@ -499,7 +443,8 @@ struct Fwd {
         std::vector<Buf*> skips;
 
         Buf* x = make(u->conv_in.cout, H, W, &rc); SISIC_TRY(rc);
-        SISIC_TRY(conv(u->conv_in, sample, cfg.in_channels, nullptr, 0, H, W, 1, 0, false, false, nullptr, nullptr, x->p, x));
+        SISIC_TRY(conv(u->conv_in, sample, cfg.in_channels, nullptr, 0, H, W, 1, 0, false, false, nullptr, nullptr, x->p, x,
+                       nullptr, nullptr, nullptr, x));
         x->refs++;                 // held by `x` and by the skip stack
         skips.push_back(x);
 
@@ -520,7 +465,8 @@ struct Fwd {
             if (i != n - 1) {
                 const int Ho = (x->H + 2 - 3) / 2 + 1, Wo = (x->W + 2 - 3) / 2 + 1;
                 Buf* y = make(u->downsamplers[i].cout, Ho, Wo, &rc); SISIC_TRY(rc);
-                SISIC_TRY(conv(u->downsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 2, 0, false, false, nullptr, nullptr, y->p, y));
+                SISIC_TRY(conv(u->downsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 2, 0, false, false, nullptr, nullptr, y->p, y,
+                               x, nullptr, nullptr, y));
                 release(x);
                 x = y;
                 x->refs++;
@@ -556,7 +502,8 @@ struct Fwd {
             }
             if (i != n - 1) {
                 Buf* y = make(u->upsamplers[i].cout, 2 * x->H, 2 * x->W, &rc); SISIC_TRY(rc);
-                SISIC_TRY(conv(u->upsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 1, 1, false, false, nullptr, nullptr, y->p, y));
+                SISIC_TRY(conv(u->upsamplers[i], x->p, x->C, nullptr, 0, x->H, x->W, 1, 1, false, false, nullptr, nullptr, y->p, y,
+                               x, nullptr, nullptr, y));
                 release(x);
                 x = y;
             }
@@ -564,7 +511,8 @@ struct Fwd {
         SISIC_REQUIRE(skips.empty(), "unet: skip stack not consumed");
         SISIC_REQUIRE(x->H == H && x->W == W, "unet: output resolution mismatch");
         SISIC_TRY(gn(x, nullptr, u->norm_out));
-        SISIC_TRY(conv(u->conv_out, x->p, x->C, nullptr, 0, H, W, 1, 0, true, true, nullptr, nullptr, out));
+        SISIC_TRY(conv(u->conv_out, x->p, x->C, nullptr, 0, H, W, 1, 0, true, true, nullptr, nullptr, out, nullptr, x, nullptr,
+                       nullptr, nullptr));
         release(x);
         return SISIC_OK;
     }
@@ -597,17 +545,38 @@ int time_embed(sisic_unet* u, int rows, hipStream_t s) {
 }
 
 int run_forward(sisic_unet* u, const float* sample, const float* tproj, int tproj_stride, float* out, int B, int H,
-                int W, hipStream_t s) {
+                int W, hipStream_t s, TrainState* tr = nullptr) {
     Fwd f{u, s, B, tproj, tproj_stride, {}};
+    f.tr = tr;
+    f.gsc = u->gn_scale; f.gsh = u->gn_shift;
     const int rc = f.run(sample, out, H, W);
-    for (auto& b : f.bufs) {           // error paths: hand everything back
+    if (tr && rc == SISIC_OK) {        // training mode: the tape owns the activations until the backward pass has run
+        for (auto& b : f.bufs) tr->bufs.push_back(std::move(b));
+        return rc;
+    }
+    for (auto& b : f.bufs) {           // inference, and error paths: hand everything back
         if (b->p) pool_put(u, b->p);
         if (b->stats) pool_put(u, b->stats);
     }
+    if (tr) tr->tape.clear();
     return rc;
 }
 
 }  // namespace
+
+namespace sisic {
+int unet_pool_get(sisic_unet* u, size_t floats, float** out) { return pool_get(u, floats, out); }
+void unet_pool_put(sisic_unet* u, float* p) { pool_put(u, p); }
+int unet_grow(float** p, size_t* have, size_t want) { return grow(p, have, want); }
+int unet_check_shape(sisic_unet* u, int B, int H, int W) { return check_shape(u, B, H, W); }
+int unet_ensure_rows(sisic_unet* u, size_t t_rows, size_t gn_rows) { return ensure_rows(u, t_rows, gn_rows); }
+int unet_stage_upload(sisic_unet* u, const float* src, size_t n, float* dst, hipStream_t s) { return stage_upload(u, src, n, dst, s); }
+int unet_prepare_all(sisic_unet* u, hipStream_t s) { return prepare_all(u, s); }
+int unet_run_forward(sisic_unet* u, const float* sample, const float* tproj, int tproj_stride, float* out, int B, int H,
+                     int W, hipStream_t s, TrainState* tape) {
+    return run_forward(u, sample, tproj, tproj_stride, out, B, H, W, s, tape);
+}
+}  // namespace sisic
 
 extern "C" {
 
@@ -638,6 +607,7 @@ int sisic_unet_create(sisic_ctx* ctx, const sisic_unet_config* cfg, sisic_unet**
 
 int sisic_unet_destroy(sisic_unet* u) {
     if (!u) return SISIC_OK;
+    (void)sisic_unet_train_end(u);
     (void)hipDeviceSynchronize();
     pool_release_all(u);
     for (auto p : u->owned) (void)hipFree(p);
@@ -689,8 +659,10 @@ int sisic_unet_load(sisic_unet* u, int n, const char* const* names, const float*
     // (re)build derived buffers
     for (auto p : u->owned) (void)hipFree(p);
     u->owned.clear();
+    reset_derived(u);
     u->loaded = false;
-    SISIC_TRY(prepare_all(u));
+    SISIC_TRY(prepare_all(u, nullptr));
+    SISIC_HIP(hipDeviceSynchronize());
     u->loaded = true;
     return SISIC_OK;
 }

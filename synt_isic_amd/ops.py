@@ -155,6 +155,49 @@ def ddpm_step(eps: torch.Tensor, x: torch.Tensor, z: Optional[torch.Tensor], coe
     return out
 
 
+def conv2d_wgrad(x: torch.Tensor, dy: torch.Tensor, ksize: int, *, x2=None, stride=1, upsample=False, gn_scale=None,
+                 gn_shift=None, gn_silu=False) -> torch.Tensor:
+    """d/dW of ``conv2d`` with the same prologue / index maps: dW [Cout, Cin, k, k] from the forward input(s) and the
+    gradient dy of the convolution's output (sisic_conv2d_wgrad)."""
+    lib = _lib.load()
+    B, c0, H, W = x.shape
+    c1 = 0 if x2 is None else x2.shape[1]
+    cout = dy.shape[1]
+    dw = torch.empty((cout, c0 + c1, ksize, ksize), dtype=torch.float32, device=x.device)
+    a = ConvArgs()
+    a.in0 = _ptr(x, "x"); a.in1 = _ptr(x2, "x2"); a.c0 = c0; a.c1 = c1
+    a.B = B; a.Hin = H; a.Win = W
+    a.upsample = int(upsample); a.ksize = ksize; a.stride = stride; a.Cout = cout
+    a.gn_scale = _ptr(gn_scale, "gn_scale"); a.gn_shift = _ptr(gn_shift, "gn_shift"); a.gn_silu = int(gn_silu)
+    check(lib.sisic_conv2d_wgrad(context(x.device), C.byref(a), _ptr(dy, "dy"), dw.data_ptr(), _stream(x.device)))
+    return dw
+
+
+def attention_bwd(qkv: torch.Tensor, out: torch.Tensor, d_out: torch.Tensor, head_dim: int = 8) -> torch.Tensor:
+    """gradient of ``attention`` w.r.t. qkv [B,3C,N]."""
+    lib = _lib.load()
+    B, C3, N = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    check(lib.sisic_attention_bwd(context(qkv.device), _ptr(qkv, "qkv"), _ptr(out, "out"), _ptr(d_out, "d_out"),
+                                  dqkv.data_ptr(), B, C3 // 3, N, head_dim, _stream(qkv.device)))
+    return dqkv
+
+
+def groupnorm_bwd(da: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,
+                  silu: bool):
+    """(dx, dgamma, dbeta) of a = act(GroupNorm(x)), act = SiLU or identity."""
+    lib = _lib.load()
+    B, Cc = x.shape[0], x.shape[1]
+    HW = x[0, 0].numel()
+    dx = torch.zeros_like(x)
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    check(lib.sisic_groupnorm_bwd(context(x.device), _ptr(da, "da"), _ptr(x, "x"), B, Cc, HW, groups, float(eps),
+                                  _ptr(gamma, "gamma"), _ptr(beta, "beta"), int(silu), dx.data_ptr(), dg.data_ptr(),
+                                  db.data_ptr(), _stream(x.device)))
+    return dx, dg, db
+
+
 DENORM_FORMS = {"image_generator": 0, "generate_test": 1, "diffusion_generator": 2}
 
 

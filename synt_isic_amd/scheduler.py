@@ -142,3 +142,31 @@ class HipDDPMScheduler:
         if not return_dict:
             return (prev,)
         return DDPMSchedulerOutput(prev_sample=prev)
+
+    def add_noise_coefficients(self, timesteps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(alphas_cumprod[t] ** 0.5, (1 - alphas_cumprod[t]) ** 0.5) as fp32 host rows, the scalars of ``add_noise``."""
+        t = torch.as_tensor(timesteps).detach().to("cpu").to(torch.int64).reshape(-1)
+        acp = self.alphas_cumprod[t]
+        return (acp ** 0.5).contiguous(), ((1 - acp) ** 0.5).contiguous()
+
+    @torch.no_grad()
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """``DDPMScheduler.add_noise`` (diffusion/train_diffusion.py:217):
+        noisy = sqrt(abar_t) * x0 + sqrt(1 - abar_t) * noise with one timestep per sample, on the GPU (sisic_add_noise)."""
+        if original_samples.device.type != "cuda":
+            raise RuntimeError("HipDDPMScheduler.add_noise runs on MI355X tensors only (no CPU path)")
+        from . import _lib
+        from ._lib import check
+        import ctypes as C
+        x0 = original_samples.to(torch.float32).contiguous()
+        nz = noise.to(device=x0.device, dtype=torch.float32).contiguous()
+        B = x0.shape[0]
+        a, c = self.add_noise_coefficients(timesteps)
+        if a.numel() != B:
+            raise ValueError(f"{a.numel()} timesteps for a batch of {B}")
+        a, c = a.to(x0.device), c.to(x0.device)
+        out = torch.empty_like(x0)
+        check(_lib.load().sisic_add_noise(ops.context(x0.device), x0.data_ptr(), nz.data_ptr(), a.data_ptr(), c.data_ptr(),
+                                          out.data_ptr(), B, x0[0].numel(),
+                                          C.c_void_p(torch.cuda.current_stream(x0.device).cuda_stream)))
+        return out

@@ -44,6 +44,22 @@ def timestep_frequencies(dim: int) -> torch.Tensor:
     return torch.exp(exponent)
 
 
+class _ParameterView:
+    """``model.parameters()``: an iterator over the tensors (``next(model.parameters()).device``,
+    image_generator.py:347-358) that also knows its model (``Adam(model.parameters(), lr)`` in the reference's training
+    loop becomes ``HipAdam(model.parameters(), lr)``)."""
+
+    def __init__(self, model, tensors):
+        self._it = iter(tensors)
+        self._sisic_model = model
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._it)
+
+
 class HipUNet2DModel:
     def __init__(self, sample_size: int = 128, in_channels: int = 3, out_channels: int = 3,
                  layers_per_block: int = 2, block_out_channels: Sequence[int] = (64, 128, 256, 256),
@@ -69,6 +85,8 @@ class HipUNet2DModel:
         self._handle: Optional[C.c_void_p] = None
         self._uploaded = False
         self.training = True                  # nn.Module default until .eval()
+        self._train_begun = False             # gradient / Adam arenas exist in the library (HipAdam creates them)
+        self._params_stale = False            # the library's weights have moved on (optimizer steps) since _params was read
 
     # ------------------------------------------------------------------ nn.Module surface
     @property
@@ -84,22 +102,61 @@ class HipUNet2DModel:
         return self
 
     def train(self, mode: bool = True) -> "HipUNet2DModel":
-        if mode:
-            raise NotImplementedError("training is out of scope: this is the sampling path only")
-        return self.eval()
-
-    def requires_grad_(self, flag: bool = False) -> "HipUNet2DModel":
-        if flag:
-            raise NotImplementedError("no backward pass: sampling only")
+        """``model.train()`` (diffusion/train_diffusion.py:209).  The network has no dropout or batch statistics, so the
+        mode only decides whether a call records the tape for ``loss.backward()`` (once an optimizer exists, synt_isic_amd.train)."""
+        self.training = bool(mode)
         return self
 
-    def parameters(self) -> Iterator[torch.Tensor]:
-        return iter(self._params.values())
+    def requires_grad_(self, flag: bool = True) -> "HipUNet2DModel":
+        return self
+
+    def _ensure_training(self) -> None:
+        """allocate the gradient and Adam arenas in the library (sisic_unet_train_begin), once"""
+        if not self._train_begun:
+            check(_lib.load().sisic_unet_train_begin(self.handle))
+            self._train_begun = True
+
+    def _refresh_params(self) -> None:
+        """after optimizer steps: read the current weights back from the library"""
+        if not self._params_stale or self._handle is None:
+            return
+        new = OrderedDict()
+        for name, t in self._read_all(0).items():
+            new[name] = t.to(self._device)
+        self._params = new
+        self._params_stale = False
+
+    def _read_all(self, what: int) -> "OrderedDict[str, torch.Tensor]":
+        lib = _lib.load()
+        h = self.handle
+        out = OrderedDict()
+        index = {lib.sisic_unet_tensor_name(h, i).decode(): i for i in range(lib.sisic_unet_num_tensors(h))}
+        for name, shape in self._spec.items():
+            t = torch.empty(tuple(shape), dtype=torch.float32)
+            check(lib.sisic_unet_read(h, what, index[name], C.cast(t.data_ptr(), _lib.c_float_p), t.numel()))
+            out[name] = t
+        return out
+
+    def grads(self) -> "OrderedDict[str, torch.Tensor]":
+        """{name: d loss / d parameter} of the last backward pass, on the host (what ``p.grad`` holds in the reference)."""
+        if not self._train_begun:
+            raise RuntimeError("no backward pass has run: create a HipAdam for this model first")
+        return self._read_all(1)
+
+    def optimizer_state(self) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:
+        return {"exp_avg": self._read_all(2), "exp_avg_sq": self._read_all(3),
+                "step": int(_lib.load().sisic_unet_train_steps(self.handle))}
+
+    def parameters(self):
+        self._refresh_params()
+        return _ParameterView(self, list(self._params.values()))
 
     def named_parameters(self):
+        self._refresh_params()
         return iter(self._params.items())
 
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        self._refresh_params()
         return OrderedDict((k, v) for k, v in self._params.items())
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
@@ -119,6 +176,7 @@ class HipUNet2DModel:
             new[name] = t.detach().to(device=self._device, dtype=torch.float32).contiguous().clone()
         self._params = new
         self._uploaded = False
+        self._params_stale = False
         if self._device.type == "cuda":
             self._upload()
         return self
@@ -131,6 +189,7 @@ class HipUNet2DModel:
             device = torch.device("cuda", torch.cuda.current_device())
         if device == self._device:
             return self
+        self._refresh_params()
         self._release()
         self._params = OrderedDict((k, v.to(device)) for k, v in self._params.items())
         self._device = device
@@ -180,12 +239,15 @@ class HipUNet2DModel:
         numels = (C.c_int64 * n)(*[t.numel() for _, t in host])
         check(lib.sisic_unet_load(self._handle, n, names, ptrs, numels))
         self._uploaded = True
+        if self._train_begun:                 # new weights under an existing optimizer: fresh moments, like a new Adam
+            check(lib.sisic_unet_train_begin(self._handle))
 
     def _release(self) -> None:
         if self._handle is not None:
             _lib.load().sisic_unet_destroy(self._handle)
             self._handle = None
             self._uploaded = False
+            self._train_begun = False
 
     def __del__(self):
         try:
@@ -229,8 +291,15 @@ class HipUNet2DModel:
         B, _, H, W = x.shape
         t = self._timesteps_host(timestep, B)
         out = torch.empty((B, self.config.out_channels, H, W), dtype=torch.float32, device=x.device)
-        check(_lib.load().sisic_unet_forward(h, x.data_ptr(), C.cast(t.data_ptr(), _lib.c_int64_p), out.data_ptr(),
-                                             B, H, W, C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        if self.training and self._train_begun:
+            # training mode with an optimizer: the same kernels, every activation kept for loss.backward()
+            check(_lib.load().sisic_unet_train_forward(h, x.data_ptr(), C.cast(t.data_ptr(), _lib.c_int64_p),
+                                                       out.data_ptr(), B, H, W, stream))
+            out._sisic_model = self
+        else:
+            check(_lib.load().sisic_unet_forward(h, x.data_ptr(), C.cast(t.data_ptr(), _lib.c_int64_p), out.data_ptr(),
+                                                 B, H, W, stream))
         if not return_dict:
             return (out,)
         return UNet2DOutput(sample=out)

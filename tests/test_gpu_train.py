@@ -1,0 +1,288 @@
+"""The training step (diffusion/train_diffusion.py:201-266) on the HIP kernels.
+
+Parity: every backward kernel against torch.autograd over a float64 evaluation of the same op (per-kernel bound
+1e-5 * max(1,|ref|)); the whole step at B=2, 3x64x64 against torch.autograd over the CPU oracle (oracle/train.py): every
+one of the 330 parameter gradients within 1e-4 * max(1, |ref|_inf), and the weights after one Adam step within fp32
+rounding of torch.optim.Adam's.  Bit-exact: add_noise, run-to-run determinism (no atomics in the backward pass).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+KTOL = 1e-5
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def _close(got, ref64, tol=KTOL, what=""):
+    got = got.detach().cpu().double()
+    bound = tol * max(1.0, ref64.abs().max().item())
+    err = (got - ref64).abs().max().item()
+    if os.environ.get("SISIC_TEST_ERRLOG"):
+        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
+            f.write(f"{err / max(1.0, ref64.abs().max().item()):.3e}\t{tol:.1e}\t{what}\n")
+    assert got.shape == ref64.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref64.shape)}"
+    assert err <= bound, f"{what}: max abs err {err:.3e} > {bound:.3e}"
+
+
+def _act64(x, x2, gn, silu, upsample):
+    x = x.double()
+    if x2 is not None:
+        x = torch.cat([x, x2.double()], 1)
+    if gn is not None:
+        x = x * gn[0].double()[:, :, None, None] + gn[1].double()[:, :, None, None]
+        if silu:
+            x = F.silu(x)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    return x
+
+
+@pytest.mark.parametrize("B,c0,c1,cout,H,W,k,stride,ups,gn,silu", [
+    (2, 64, 0, 64, 64, 64, 3, 1, False, True, True),       # ResBlock conv at full resolution
+    (2, 20, 12, 70, 18, 10, 3, 1, False, True, True),      # concat seam inside a tile, ragged edges, Cout % 64 != 0
+    (3, 40, 0, 33, 8, 8, 3, 1, False, False, False),       # 8x8 level
+    (2, 96, 32, 128, 16, 16, 3, 1, False, True, False),
+    (2, 24, 0, 64, 10, 14, 3, 1, True, False, False),      # nearest-2x upsampler
+    (2, 64, 0, 64, 32, 32, 3, 2, False, False, False),     # stride-2 downsampler
+    (2, 48, 0, 40, 12, 20, 3, 2, False, False, False),
+    (2, 64, 64, 128, 16, 16, 1, 1, False, False, False),   # 1x1 shortcut over a concatenation
+    (2, 256, 0, 768, 8, 8, 1, 1, False, True, False),      # fused q/k/v projection (GroupNorm prologue, no SiLU)
+    (1, 3, 0, 64, 32, 32, 3, 1, False, False, False),      # conv_in
+    (2, 64, 0, 3, 32, 32, 3, 1, False, True, True),        # conv_out
+])
+def test_conv_wgrad(B, c0, c1, cout, H, W, k, stride, ups, gn, silu):
+    from synt_isic_amd import ops
+    x = _rand(B, c0, H, W, seed=1)
+    x2 = _rand(B, c1, H, W, seed=2) if c1 else None
+    g = (1.0 + 0.3 * _rand(B, c0 + c1, seed=3), 0.3 * _rand(B, c0 + c1, seed=4)) if gn else None
+    a = _act64(x, x2, g, silu, ups)
+    w = torch.zeros(cout, c0 + c1, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(a, w, stride=stride, padding=k // 2)
+    dy = _rand(*y.shape, seed=5)
+    y.backward(dy.double())
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    got = ops.conv2d_wgrad(d(x), d(dy), k, x2=d(x2), stride=stride, upsample=ups, gn_scale=d(g[0]) if gn else None,
+                           gn_shift=d(g[1]) if gn else None, gn_silu=silu)
+    _close(got, w.grad, what=f"conv wgrad {c0}+{c1}->{cout} k{k} s{stride} ups{int(ups)} {H}x{W}")
+    assert torch.equal(got, ops.conv2d_wgrad(d(x), d(dy), k, x2=d(x2), stride=stride, upsample=ups,
+                                             gn_scale=d(g[0]) if gn else None, gn_shift=d(g[1]) if gn else None,
+                                             gn_silu=silu))          # fixed-order K-split reduction: bit-reproducible
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 256, 64), (1, 128, 256), (2, 64, 1024), (1, 32, 100)])
+def test_attention_bwd(B, C, N):
+    from synt_isic_amd import ops
+    qkv = _rand(B, 3 * C, N, seed=10)
+    dO = _rand(B, C, N, seed=11)
+    q64 = qkv.double().requires_grad_(True)
+    heads = C // 8
+    q, k, v = (t.reshape(B, heads, 8, N).transpose(2, 3) for t in q64.chunk(3, dim=1))
+    p = torch.softmax(q @ k.transpose(-1, -2) * 8 ** -0.5, dim=-1)
+    o = (p @ v).transpose(2, 3).reshape(B, C, N)
+    o.backward(dO.double())
+    out = ops.attention(qkv.to(DEV))
+    got = ops.attention_bwd(qkv.to(DEV), out, dO.to(DEV))
+    _close(got, q64.grad, what=f"attention bwd C={C} N={N}")
+
+
+@pytest.mark.parametrize("B,C,H,W,silu", [(2, 64, 16, 16, True), (3, 128, 8, 8, False), (2, 320, 10, 6, True)])
+def test_groupnorm_bwd(B, C, H, W, silu):
+    from synt_isic_amd import ops
+    x = _rand(B, C, H, W, seed=20) * 1.7 + 0.4
+    gamma, beta = 1.0 + 0.2 * _rand(C, seed=21), 0.2 * _rand(C, seed=22)
+    da = _rand(B, C, H, W, seed=23)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.group_norm(x64, 32, g64, b64, eps=1e-5)
+    if silu:
+        a = F.silu(a)
+    a.backward(da.double())
+    dx, dg, db = ops.groupnorm_bwd(da.to(DEV), x.to(DEV), gamma.to(DEV), beta.to(DEV), 32, 1e-5, silu)
+    _close(dx, x64.grad, what="groupnorm bwd dx")
+    _close(dg, g64.grad, what="groupnorm bwd dgamma")
+    _close(db, b64.grad, what="groupnorm bwd dbeta")
+
+
+def test_add_noise_bit_exact():
+    """scheduler.add_noise (train_diffusion.py:217): same fp32 products and sum as the published torch expression."""
+    from oracle import ddpm as oddpm
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    x0 = _rand(5, 3, 32, 32, seed=30).clamp(-1, 1)
+    nz = _rand(5, 3, 32, 32, seed=31)
+    t = torch.tensor([0, 1, 500, 998, 999])
+    s = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
+    got = s.add_noise(x0.to(DEV), nz.to(DEV), t.to(DEV)).cpu()
+    assert torch.equal(got, oddpm.DDPMSchedulerOracle().add_noise(x0, nz, t))
+
+
+@pytest.fixture(scope="module")
+def batch():
+    g = torch.Generator().manual_seed(77)
+    images = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1)
+    noise = torch.randn(2, 3, 64, 64, generator=g)
+    timesteps = torch.tensor([37, 912])
+    return images, noise, timesteps
+
+
+@pytest.fixture(scope="module")
+def reference(synthetic_sd, batch):
+    from oracle import train as otrain
+    loss, grads, pred = otrain.loss_and_grads(synthetic_sd, *batch)
+    return loss, grads, pred
+
+
+def _new_model(sd):
+    from synt_isic_amd.unet import HipUNet2DModel
+    m = HipUNet2DModel()
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def test_unet_gradients_match_autograd_over_the_oracle(synthetic_sd, batch, reference):
+    """B=2, 3x64x64: loss, prediction and every one of the 330 parameter gradients of one training batch against
+    torch.autograd over the CPU oracle; the reference's loop spelled with the Hip* stand-ins."""
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    from synt_isic_amd.train import HipAdam, mse_loss
+    images, noise, timesteps = (t.to(DEV) for t in batch)
+    ref_loss, ref_grads, ref_pred = reference
+    model = _new_model(synthetic_sd)
+    scheduler = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
+    optimizer = HipAdam(model.parameters(), lr=1e-4)
+    model.train()
+    noisy = scheduler.add_noise(images, noise, timesteps)
+    noise_pred = model(noisy, timesteps).sample
+    assert (noise_pred.cpu() - ref_pred).abs().max().item() <= 2e-4
+    model.eval()
+    assert torch.equal(model(noisy, timesteps).sample, noise_pred)        # the tape-recording forward IS the forward
+    model.train()
+    noise_pred = model(noisy, timesteps).sample
+    loss = mse_loss(noise_pred, noise)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    grads = model.grads()
+    assert list(grads) == list(ref_grads) and len(grads) == 330
+    worst = ("", 0.0)
+    for name, ref in ref_grads.items():
+        err = (grads[name] - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        if os.environ.get("SISIC_TEST_ERRLOG"):
+            with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
+                f.write(f"{err:.3e}\t1.0e-04\tgrad {name} (|ref|max {ref.abs().max().item():.3e})\n")
+        if err > worst[1]:
+            worst = (name, err)
+    assert worst[1] <= 1e-4, f"gradient of {worst[0]}: {worst[1]:.3e} of max(1,|ref|)"
+    # the gradients are not just small: relative to each tensor's own scale they agree too (median over tensors)
+    # (to_k.bias has an identically zero gradient -- softmax is invariant to a shift of the keys' scores -- so tensors whose
+    # reference gradient is below 1e-8 are left out of the relative measure)
+    rel = sorted((grads[n] - r).abs().max().item() / r.abs().max().item() for n, r in ref_grads.items()
+                 if r.abs().max().item() > 1e-8)
+    if os.environ.get("SISIC_TEST_ERRLOG"):
+        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
+            f.write(f"{rel[len(rel) // 2]:.3e}\t{rel[-1]:.3e}\trelative gradient error: median / max over {len(rel)} tensors\n")
+    assert rel[len(rel) // 2] <= 1e-3 and rel[-1] <= 5e-2, (rel[len(rel) // 2], rel[-1])
+    # bit-reproducible: a second forward/backward of the same batch gives the same gradients
+    noise_pred2 = model(noisy, timesteps).sample
+    mse_loss(noise_pred2, noise).backward()
+    again = model.grads()
+    assert all(torch.equal(again[n], grads[n]) for n in grads)
+
+
+def test_one_adam_step_matches_torch_adam(synthetic_sd, batch, reference):
+    """scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update() (train_diffusion.py:231-233) against
+    torch.optim.Adam(lr=1e-4) over the oracle's gradients: after step 1 every weight has moved by ~lr * sign(grad), so the
+    comparison is in units of lr; then the Adam kernel alone against torch.optim.Adam on IDENTICAL gradients (fp32 rounding)."""
+    from oracle import train as otrain
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    from synt_isic_amd.train import HipAdam, HipGradScaler, mse_loss
+    images, noise, timesteps = (t.to(DEV) for t in batch)
+    _, ref_grads, _ = reference
+    model = _new_model(synthetic_sd)
+    scheduler = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
+    optimizer = HipAdam(model.parameters(), lr=1e-4)
+    scaler = HipGradScaler()
+    model.train()
+    loss = mse_loss(model(scheduler.add_noise(images, noise, timesteps), timesteps).sample, noise)
+    optimizer.zero_grad(set_to_none=True)
+    scaler.scale(loss).backward()
+    scaled = model.grads()
+    assert scaler.step(optimizer) is True
+    scaler.update()
+    assert scaler.get_scale() == 65536.0
+    after = model.state_dict()
+    assert model.optimizer_state()["step"] == 1
+    # (a) loss scaling by 65536 is exact in fp32 (a power of two): the scaled gradients are 65536 x the unscaled ones
+    ref_new, _ = otrain.adam_step(synthetic_sd, ref_grads)
+    big = 0.0
+    for name in ref_new:
+        move_ref = ref_new[name] - synthetic_sd[name]
+        move = after[name].cpu() - synthetic_sd[name]
+        # where |grad| >> eps the first Adam step is lr * sign(grad): compare the moves where the reference gradient is
+        # clear of the noise floor of the gradient parity (1e-4 * max(1,|g|))
+        clear = ref_grads[name].abs() > 1e-3 * max(1.0, ref_grads[name].abs().max().item())
+        if clear.any():
+            big = max(big, (move - move_ref)[clear].abs().max().item())
+    assert big <= 2e-7, f"largest difference of a weight move: {big:.3e} (lr = 1e-4)"
+    # (b) the Adam kernel on identical gradients: feed torch.optim.Adam the GPU's own (unscaled) gradients
+    unscaled = {k: v / 65536.0 for k, v in scaled.items()}
+    same_new, _ = otrain.adam_step(synthetic_sd, unscaled)
+    worst = max((after[k].cpu() - same_new[k]).abs().max().item() for k in same_new)
+    assert worst <= 3e-9 + 2 ** -22, f"Adam kernel vs torch.optim.Adam on the same gradients: {worst:.3e}"
+    st = model.optimizer_state()
+    k = "mid_block.resnets.0.conv1.weight"
+    assert torch.allclose(st["exp_avg"][k], 0.1 * unscaled[k], rtol=1e-5, atol=1e-12)
+    assert torch.allclose(st["exp_avg_sq"][k], 0.001 * unscaled[k] ** 2, rtol=1e-5, atol=1e-20)
+
+
+def test_grad_scaler_skips_a_step_with_non_finite_gradients(synthetic_sd, batch):
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    from synt_isic_amd.train import HipAdam, HipGradScaler, mse_loss
+    images, noise, timesteps = (t.to(DEV) for t in batch)
+    model = _new_model(synthetic_sd)
+    scheduler = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
+    optimizer = HipAdam(model.parameters(), lr=1e-4)
+    scaler = HipGradScaler(init_scale=3.0e38)                      # overflows the scaled gradients
+    model.train()
+    loss = mse_loss(model(scheduler.add_noise(images, noise, timesteps), timesteps).sample, noise)
+    scaler.scale(loss).backward()
+    assert scaler.step(optimizer) is False                         # skipped
+    scaler.update()
+    assert scaler.get_scale() == 1.5e38 and model.optimizer_state()["step"] == 0
+    after = model.state_dict()
+    assert all(torch.equal(after[k].cpu(), synthetic_sd[k]) for k in synthetic_sd)
+
+
+def test_training_loop_overfits_one_batch_and_fused_step_agrees(synthetic_sd, tmp_path):
+    """train_class (train_diffusion.py:187-266) on a loader of one fixed batch: the loss falls, the best checkpoint is a
+    loadable state dict, the fused sisic_unet_train_step takes the same steps as the spelled-out loop, and the trained
+    weights sample (eval mode) without touching the training state."""
+    from synt_isic_amd.train import train_class
+    g = torch.Generator().manual_seed(5)
+    images = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    loader = [images] * 4
+
+    def run(fused):
+        m = _new_model(synthetic_sd)
+        hist = train_class(m, loader, "NV", epochs=3, lr=1e-4, checkpoint_dir=str(tmp_path / ("f" if fused else "s")),
+                           fused=fused, generator=torch.Generator().manual_seed(9), log=None)
+        return m, hist
+
+    m1, h1 = run(True)
+    m2, h2 = run(False)
+    assert len(h1) == 3 and h1[-1] < h1[0], h1
+    assert np.allclose(h1, h2, rtol=1e-6, atol=0), (h1, h2)
+    sd1, sd2 = m1.state_dict(), m2.state_dict()
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+    assert any(not torch.equal(sd1[k].cpu(), synthetic_sd[k]) for k in sd1)
+    ck = torch.load(str(tmp_path / "f" / "unet_NV_best.pth"))
+    m3 = _new_model(ck)
+    x = torch.randn(1, 3, 32, 32, generator=g).to(DEV)
+    assert torch.equal(m3.eval()(x, 10).sample, m1.eval()(x, 10).sample)

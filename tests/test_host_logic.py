@@ -114,8 +114,11 @@ def test_no_cpu_fallback():
     m.load_state_dict(weights.synthetic_unet_state_dict())
     with pytest.raises(RuntimeError, match="MI355X only"):
         m(torch.zeros(1, 3, 64, 64), 10)
-    with pytest.raises(NotImplementedError):
-        m.train()
+    # training mode exists but, like everything else, only on the GPU: no optimizer on a CPU model
+    assert m.train() is m and m.training and m.eval().training is False
+    from synt_isic_amd.train import HipAdam
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        HipAdam(m.parameters(), lr=1e-4)
     with pytest.raises(NotImplementedError):
         unet.HipUNet2DModel(class_embed_type="timestep")
 
