@@ -209,7 +209,8 @@ int sisic_unet_train_end(sisic_unet*);
 int sisic_add_noise(sisic_ctx*, const float* x0, const float* noise, const float* sqrt_alpha_prod,
                     const float* sqrt_one_minus_alpha_prod, float* out, int B, int64_t per_sample, void* stream);
 /* noise_pred = model(noisy, timesteps).sample in training mode (train_diffusion.py:218): the inference kernels, every
- * activation and GroupNorm statistic kept for the backward pass.  timesteps: host int64 [B], one per sample.          */
+ * activation and GroupNorm statistic kept for the backward pass.  timesteps: host int64 [B], one per sample.
+ * `sample` is read again by sisic_unet_backward (conv_in's weight gradient): it must stay valid until then.          */
 int sisic_unet_train_forward(sisic_unet*, const float* sample, const int64_t* timesteps, float* out, int B, int H, int W,
                              void* stream);
 /* F.mse_loss(pred, target) (train_diffusion.py:219): loss_dev[0] = mean((pred - target)^2) (NULL: kept internally),

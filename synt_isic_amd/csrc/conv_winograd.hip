@@ -80,11 +80,23 @@ constexpr int W_SLAB = W_CIC * 16 * 64;   // floats of one U or V buffer (32 KiB
 
 // Makes a wave-uniform pointer provably uniform for hipcc (two v_readfirstlane), so that the loads through it use the
 // scalar-base form  global_load v, v_offset32, s[base:base+1]  instead of per-lane 64-bit address arithmetic.
-__device__ __forceinline__ const char* uniform_ptr(const void* ptr) {
+// The result is typed as a GLOBAL (address space 1) pointer: rebuilt from two integers the pointer would otherwise be
+// generic and every load through it a flat_load, which counts in lgkmcnt as well as vmcnt -- the s_waitcnt lgkmcnt(0) in
+// front of each MFMA's LDS operands then also waited for the global prefetches issued just before (found in the ISA of
+// round 1's kernel: 1501 flat_load against 553 global_load).
+typedef const __attribute__((address_space(1))) char* gcptr_t;
+typedef const __attribute__((address_space(1))) float* gfptr_t;
+typedef float v4f_t __attribute__((ext_vector_type(4)));     // plain vector types: HIP's float4 / float2 are classes whose
+typedef float v2f_t __attribute__((ext_vector_type(2)));     // constructors do not bind to address-space-1 references
+typedef const __attribute__((address_space(1))) v4f_t* gf4ptr_t;
+typedef const __attribute__((address_space(1))) v2f_t* gf2ptr_t;
+typedef __attribute__((address_space(1))) float* gfwptr_t;
+typedef __attribute__((address_space(1))) v2f_t* gf2wptr_t;
+__device__ __forceinline__ gcptr_t uniform_ptr(const void* ptr) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    return (gcptr_t)(((unsigned long long)hi << 32) | lo);
 }
 
 // x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp): __fdividef expands to the 10-instruction IEEE
@@ -259,13 +271,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
         const int hcc = h.hcc = min(c, Cin - 1);
         const bool first = hcc < p.c0;
         const int csrc = first ? p.c0 : p.c1;
-        const char* plane = uniform_ptr(
+        const gcptr_t plane = uniform_ptr(
             first ? p.in0 + ((size_t)b0 * p.c0 + hcc) * HWin : p.in1 + ((size_t)b0 * p.c1 + (hcc - p.c0)) * HWin);
         const unsigned img_stride = 4u * (unsigned)(csrc * HWin);
 #pragma unroll
         for (int i = 0; i < G::EPT; ++i) {
             const unsigned vo = (NIMG > 1) ? (unsigned)gimg[i] * img_stride + goff[i] : goff[i];
-            h.v[i] = *reinterpret_cast<const float*>(plane + vo);
+            h.v[i] = *(gfptr_t)(plane + vo);
         }
         if constexpr (PRO != 0) {
             h.gsc = p.gn_scale[b0 * Cin + hcc];            // uniform index: scalar loads.  NIMG > 1: see stage_halo
@@ -284,10 +296,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
     const bool u_active = !UPS || !((WINO_UPS_ZERO >> ((tid >> 4) & 15)) & 1u);
     auto load_u = [&](int chunk, FilterRegs& f) {
         if (!u_active) return;
-        const char* slab = uniform_ptr(p.u + (size_t)(cbase + chunk) * W_CIC * 16 * p.cout_pad + co0);
+        const gcptr_t slab = uniform_ptr(p.u + (size_t)(cbase + chunk) * W_CIC * 16 * p.cout_pad + co0);
 #pragma unroll
         for (int i = 0; i < G::UPT; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(slab + uoff[i]);
+            const v4f_t t = *(gf4ptr_t)(slab + uoff[i]);
             f.w[4 * i + 0] = t.x; f.w[4 * i + 1] = t.y; f.w[4 * i + 2] = t.z; f.w[4 * i + 3] = t.w;
         }
     };
@@ -585,13 +597,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             if (p.chan_bias && !p.part) add += p.chan_bias[(size_t)ebc * p.chan_bias_stride + coc];
             eadd[q][k] = add;
             const size_t plane = ((size_t)ebc * p.Cout + coc) * HWout;
-            const float* rb = p.residual + plane;
-            if constexpr (SCALAR_PLANE) rb = reinterpret_cast<const float*>(uniform_ptr(rb));
+            gfptr_t rb = (gfptr_t)(p.residual + plane);
+            if constexpr (SCALAR_PLANE) rb = (gfptr_t)uniform_ptr(p.residual + plane);
             if (p.residual && !p.part) {
                 if (pair_ok) {          // even row length: the thread's two pixels of a row are one aligned float2
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const float2 t = *reinterpret_cast<const float2*>(rb + eoff[i][0]);
+                        const v2f_t t = *(gf2ptr_t)(rb + eoff[i][0]);
                         eres[q][k][i][0] = t.x;
                         eres[q][k][i][1] = t.y;
                     }
@@ -664,8 +676,8 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
             const int co = round_co(q, k);
             const bool ok = co < p.Cout && eb < p.B;
             const size_t plane = ((size_t)ebc * p.Cout + min(co, p.Cout - 1)) * HWout;
-            float* db = edst + plane;
-            if constexpr (SCALAR_PLANE) db = const_cast<float*>(reinterpret_cast<const float*>(uniform_ptr(db)));
+            gfwptr_t db = (gfwptr_t)(edst + plane);
+            if constexpr (SCALAR_PLANE) db = (gfwptr_t)uniform_ptr(edst + plane);
             float vv[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -676,7 +688,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) conv_winograd_kernel(const Wi
                     if (!pair_ok && ok && pin[i][j]) db[eoff[i][j]] = v;
                     vv[i][j] = v;
                 }
-                if (pair_ok && ok && pin[i][0]) *reinterpret_cast<float2*>(db + eoff[i][0]) = make_float2(vv[i][0], vv[i][1]);
+                if (pair_ok && ok && pin[i][0]) *(gf2wptr_t)(db + eoff[i][0]) = v2f_t{vv[i][0], vv[i][1]};
             }
             if (!WINO_TIMING && p.stats && !p.part) {
                 // One output channel per wave here; lanes are the 64 tiles: all of one image (NIMG == 1) or 16 per

@@ -86,6 +86,7 @@ class HipUNet2DModel:
         self._uploaded = False
         self.training = True                  # nn.Module default until .eval()
         self._train_begun = False             # gradient / Adam arenas exist in the library (HipAdam creates them)
+        self._tape_input = None               # input of the last training-mode forward (the tape points into it)
         self._params_stale = False            # the library's weights have moved on (optimizer steps) since _params was read
 
     # ------------------------------------------------------------------ nn.Module surface
@@ -297,6 +298,9 @@ class HipUNet2DModel:
             check(_lib.load().sisic_unet_train_forward(h, x.data_ptr(), C.cast(t.data_ptr(), _lib.c_int64_p),
                                                        out.data_ptr(), B, H, W, stream))
             out._sisic_model = self
+            # the tape refers to the input by address (conv_in's weight gradient reads it in the backward pass): keep the
+            # tensor alive until the next forward, as autograd's graph would
+            self._tape_input = x
         else:
             check(_lib.load().sisic_unet_forward(h, x.data_ptr(), C.cast(t.data_ptr(), _lib.c_int64_p), out.data_ptr(),
                                                  B, H, W, stream))

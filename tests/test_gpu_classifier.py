@@ -53,7 +53,7 @@ def test_conv7x7_stride2(cfg, H, W):
     b = torch.randn(64, generator=torch.Generator().manual_seed(3))
     got = ops.conv2d(x.to(DEV), ops.pack_conv_weight(w.to(DEV)), 64, 7, bias=b.to(DEV), stride=2, relu=True, tile_cfg=cfg)
     ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=3))
-    _close(got, ref, 2e-5, f"conv7x7 s2 {H}x{W}")
+    _close(got, ref, 1e-5, f"conv7x7 s2 {H}x{W}")
 
 
 @pytest.mark.parametrize("cfg,H,W,cin,cout", [(0, 56, 56, 64, 128), (31, 56, 56, 64, 128), (32, 28, 28, 128, 256),
@@ -64,7 +64,7 @@ def test_conv1x1_stride2(cfg, H, W, cin, cout):
     w = torch.randn(cout, cin, 1, 1, generator=torch.Generator().manual_seed(6)) * 0.1
     b = torch.randn(cout, generator=torch.Generator().manual_seed(7))
     got = ops.conv2d(x.contiguous().to(DEV), ops.pack_conv_weight(w.to(DEV)), cout, 1, bias=b.to(DEV), stride=2, tile_cfg=cfg)
-    _close(got, F.conv2d(x.double(), w.double(), b.double(), stride=2), 2e-5, f"conv1x1 s2 {H}x{W}")
+    _close(got, F.conv2d(x.double(), w.double(), b.double(), stride=2), 1e-5, f"conv1x1 s2 {H}x{W}")
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 64, 64), (2, 128, 128), (1, 224, 224), (2, 96, 40)])
@@ -201,11 +201,11 @@ def test_zero_insertion_conv_is_the_transposed_stride2_conv():
     got = ops.conv2d(dy.to(DEV), ops.pack_conv_weight(wt.to(DEV)), cin, 3, upsample=2)
     ref = F.conv_transpose2d(dy.double(), w.double(), stride=2, padding=1, output_padding=1)
     assert got.shape == ref.shape == (B, cin, H, H)
-    assert (got.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
     # and it is what autograd computes for the forward convolution
     x = torch.randn(B, cin, H, H, generator=g, dtype=torch.float64, requires_grad=True)
     F.conv2d(x, w.double(), stride=2, padding=1).backward(dy.double())
-    assert (got.cpu().double() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
+    assert (got.cpu().double() - x.grad).abs().max().item() <= 1e-5 * max(1.0, x.grad.abs().max().item())
 
 
 @pytest.mark.parametrize("B,H,W,target", [(2, 64, 64, 1), (3, 128, 128, 4), (1, 40, 56, 0), (2, 224, 224, 6), (1, 96, 96, 2)])
@@ -239,15 +239,20 @@ def test_input_gradient_matches_autograd_of_the_oracle(clf, clf_sd, B, H, W, tar
     assert strict >= 1
 
 
-REPLAY_TOL = 1e-3
+REPLAY_TOL = 1e-3       # one ReLU of the 17 flipping at a pre-activation within rounding of zero moves the gradient by ~4e-4
+STRICT_TOL = 1e-5
 
 
 @pytest.mark.parametrize("B,H,W,target", [(2, 64, 64, 1), (3, 128, 128, 4), (2, 224, 224, 6)])
 def test_input_gradient_max_abs_when_the_pool_routes_are_replayed(clf, clf_sd, B, H, W, target):
-    """The arg-max-tie explanation of the statistical test above, demonstrated: the CPU autograd pass is given the GPU's
-    own stem activation (values only; the gradient still flows through the CPU graph), so its max-pool takes the routes
-    the GPU took.  With the routes equal the two gradients agree EVERYWHERE: max-abs <= 2e-5 of the largest gradient on
-    every image -- no fraction, no cosine -- and the stem activations themselves agree to fp32 rounding."""
+    """The arg-max-tie explanation of the statistical test above, demonstrated.  The CPU autograd pass is run twice: with
+    its own max-pool routes ("free"), and with the GPU's own stem activation substituted (values only; the gradient still
+    flows through the CPU graph), so that its max-pool takes the routes the GPU took ("replayed").  Measured (r02, errlog):
+    the images whose free-route error is 7e-3 / 1e-1 of the largest gradient drop to 2e-6 / 4e-6 once the routes are
+    replayed -- the whole discrepancy was the route -- and on every image at least one of the two CPU passes agrees with the
+    GPU EVERYWHERE to <= 1e-5 of the largest gradient (max-abs, no fraction, no cosine).  The replayed pass itself is bounded
+    by 1e-3: substituting the stem perturbs every later activation by ~1e-6, which now and then flips one ReLU whose
+    pre-activation is within rounding of zero (one such flip measured: 3.7e-4)."""
     from oracle import resnet18 as ores
     g = torch.Generator().manual_seed(100 + H)                 # the same inputs as the statistical test
     x = torch.rand(B, 3, H, W, generator=g) * 1.6 - 0.8
@@ -256,9 +261,9 @@ def test_input_gradient_max_abs_when_the_pool_routes_are_replayed(clf, clf_sd, B
     with torch.no_grad():
         h = ores.preprocess_for_classifier(x)
         h = F.relu(ores._bn(clf_sd, "model.bn1", F.conv2d(h, clf_sd["model.conv1.weight"], None, stride=2, padding=3)))
-    assert (stem - h).abs().max().item() <= 2e-5 * max(1.0, h.abs().max().item())
+    assert (stem - h).abs().max().item() <= 1e-5 * max(1.0, h.abs().max().item())
     ref_g, ref_l = ores.score_input_gradient(clf_sd, x, target, stem_override=stem)
-    free_g, _ = ores.score_input_gradient(clf_sd, x, target)                  # the CPU's own routes, for comparison
+    free_g, _ = ores.score_input_gradient(clf_sd, x, target)                  # the CPU's own routes
     assert (logits.cpu() - ref_l).abs().max().item() <= 2e-4 * max(1.0, ref_l.abs().max().item())
     for b in range(B):
         scale = ref_g[b].abs().max().item()
@@ -267,7 +272,8 @@ def test_input_gradient_max_abs_when_the_pool_routes_are_replayed(clf, clf_sd, B
         if os.environ.get("SISIC_TEST_ERRLOG"):
             with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
                 f.write(f"{err / scale:.3e}\t{err_free / scale:.3e}\tinput_gradient replayed/free routes B{B} {H}x{W} image {b}\n")
-        assert err <= REPLAY_TOL * scale, f"image {b}: max|dgrad| = {err:.3e} vs scale {scale:.3e}"
+        assert err <= REPLAY_TOL * scale, f"image {b}: replayed routes max|dgrad| = {err:.3e} vs scale {scale:.3e}"
+        assert min(err, err_free) <= STRICT_TOL * scale, f"image {b}: replayed {err / scale:.3e}, free {err_free / scale:.3e}"
 
 
 def test_input_gradient_is_the_directional_derivative(clf):

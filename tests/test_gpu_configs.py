@@ -94,6 +94,7 @@ def test_config5_512_classifier_forwards(clf):
     logits = clf(xd)
     assert logits.shape == (512, 7) and torch.isfinite(logits).all()
     assert torch.equal(logits, clf(xd))                                        # deterministic
+    big = clf.workspace_bytes()                                                # pool of the 512-image pass
     for lo in (0, 255, 509):
         assert torch.equal(clf(xd[lo:lo + 3]), logits[lo:lo + 3])
     sd = synthetic_resnet18_state_dict()
@@ -101,7 +102,6 @@ def test_config5_512_classifier_forwards(clf):
     ref = ores.classifier_forward(sd, x[idx])
     assert (logits[idx].cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
     # the workspace of the pass is released when the shape changes (the pool used to grow only)
-    big = clf.workspace_bytes()
     clf(xd[:4])
     assert 0 < clf.workspace_bytes() < big / 16
 

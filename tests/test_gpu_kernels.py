@@ -1,7 +1,9 @@
 """Per-kernel parity: each HIP kernel, called through the C ABI, against the CPU oracle's torch op.
 
-Tolerance: fp32 kernels max-abs <= 2e-5 * max(1, |ref|_inf) against a float64
-evaluation of the same op; the scheduler step, the de-normalisation and everything integer are bit-exact.
+Tolerance (unchanged): fp32 kernels max-abs <= 1e-5 * max(1, |ref|_inf) against a float64
+evaluation of the same op (round 1 ran these at 2e-5 / 3e-5; the largest error measured over all 974 comparisons of this
+file on MI355X is 3.6e-6, tools: SISIC_TEST_ERRLOG); the scheduler step, the de-normalisation and everything integer are
+bit-exact.
 """
 import itertools
 
@@ -15,6 +17,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
+KTOL = 1e-5          # per kernel max-abs <= 1e-5 * max(1, |ref|_inf) vs a float64 evaluation
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -22,7 +25,7 @@ def _rand(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-def _close(got: torch.Tensor, ref64: torch.Tensor, tol=2e-5, what=""):
+def _close(got: torch.Tensor, ref64: torch.Tensor, tol=KTOL, what=""):
     got = got.detach().cpu().double()
     bound = tol * max(1.0, ref64.abs().max().item())
     err = (got - ref64).abs().max().item()
@@ -182,10 +185,10 @@ def test_conv3x3_winograd(cfg, B, H, W):
     cb = _rand(B, cout, seed=116)
     res = _rand(B, cout, H, W, seed=117)
     kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True, chan_bias=cb, residual=res)
-    _close(_run_wino(x, w, cfg, **kw), _conv_ref(x, w, **kw), tol=3e-5, what=f"winograd fused cfg{cfg}")
+    _close(_run_wino(x, w, cfg, **kw), _conv_ref(x, w, **kw), tol=KTOL, what=f"winograd fused cfg{cfg}")
     kw = dict(bias=b, x2=x2, gn=gn, gn_silu=False, relu=True, chan_bias=cb[0])
     ref = _conv_ref(x, w, bias=b, x2=x2, gn=gn, relu=True, chan_bias=cb[0:1].expand(B, -1))
-    _close(_run_wino(x, w, cfg, **kw), ref, tol=3e-5, what=f"winograd fused 2 cfg{cfg}")
+    _close(_run_wino(x, w, cfg, **kw), ref, tol=KTOL, what=f"winograd fused 2 cfg{cfg}")
 
 
 @pytest.mark.parametrize("cfg,H,W", [(60, 16, 16), (60, 8, 8), (60, 10, 14), (61, 4, 4), (62, 16, 16), (62, 10, 14),
@@ -218,14 +221,14 @@ def test_conv3x3_winograd_ksplit(B, H, W, c0, c1, cout):
     cb = _rand(B, cout, seed=196)
     res = _rand(B, cout, H, W, seed=197)
     kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True, chan_bias=cb, residual=res)
-    _close(_run_wino(x, w, 90, **kw), _conv_ref(x, w, **kw), tol=3e-5, what="winograd K-split fused")
+    _close(_run_wino(x, w, 90, **kw), _conv_ref(x, w, **kw), tol=KTOL, what="winograd K-split fused")
     kw = dict(bias=b, x2=x2, relu=True)
-    _close(_run_wino(x, w, 90, **kw), _conv_ref(x, w, **kw), tol=3e-5, what="winograd K-split relu")
+    _close(_run_wino(x, w, 90, **kw), _conv_ref(x, w, **kw), tol=KTOL, what="winograd K-split relu")
     d = lambda t: None if t is None else t.to(DEV).contiguous()
     cfg = 0 if (H, W, c0 + c1, cout) == (8, 8, 128, 128) else 90      # the last case is what the auto dispatch picks
     y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 3, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=cfg,
                        w_winograd=ops.pack_winograd_weight(d(w)), with_stats=True)
-    _close(y, _conv_ref(x, w, bias=b, x2=x2, residual=res), tol=3e-5, what="winograd K-split + stats")
+    _close(y, _conv_ref(x, w, bias=b, x2=x2, residual=res), tol=KTOL, what="winograd K-split + stats")
     assert st is not None and tuple(st.shape) == (B, cout, 1, 4)
     G = 2 if cout % 32 else 32
     gamma, beta = 1.0 + 0.1 * _rand(cout, seed=198), 0.1 * _rand(cout, seed=199)
@@ -233,7 +236,7 @@ def test_conv3x3_winograd_ksplit(B, H, W, c0, c1, cout):
     yc = y.cpu().double()
     ref = F.group_norm(yc, G, gamma.double(), beta.double(), 1e-5)
     got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
-    _close(got.float(), ref, tol=2e-5, what="groupnorm from K-split reduction partials")
+    _close(got.float(), ref, tol=KTOL, what="groupnorm from K-split reduction partials")
     from synt_isic_amd._lib import SisicError
     with pytest.raises(SisicError, match="split"):
         _run_wino(x[:, :24].contiguous(), w[:, :24].contiguous(), 90)        # 3 chunks do not split four ways
@@ -343,12 +346,12 @@ def test_groupnorm_stats(c0, c1, H, W):
     full = (torch.cat([x, x2], 1) if c1 else x).double()
     ref = F.group_norm(full, G, gamma.double(), beta.double(), eps)
     got = full * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
-    _close(got.float(), ref, tol=2e-5, what="groupnorm apply")
+    _close(got.float(), ref, tol=KTOL, what="groupnorm apply")
     # the fused consumer: conv(SiLU(GN(x))) == oracle composition
     w = _rand(64, C, 3, 3, seed=34, scale=0.05)
     wp = ops.pack_conv_weight(w.to(DEV))
     y = ops.conv2d(x.to(DEV), wp, 64, 3, x2=x2.to(DEV) if c1 else None, gn_scale=sc, gn_shift=sh, gn_silu=True)
-    _close(y, F.conv2d(F.silu(ref), w.double(), padding=1), tol=3e-5, what="GN+SiLU+conv")
+    _close(y, F.conv2d(F.silu(ref), w.double(), padding=1), tol=KTOL, what="GN+SiLU+conv")
 
 
 def test_groupnorm_large_mean_is_stable():
@@ -393,7 +396,7 @@ def test_conv_epilogue_groupnorm_partials(cfg, B, H, W, ups):
     _close(sh, sh0.cpu().double(), tol=2e-6, what="finalize shift")
     ref = F.group_norm(yc, G, gamma.double(), beta.double(), eps)
     got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
-    _close(got.float(), ref, tol=2e-5, what="groupnorm from partials")
+    _close(got.float(), ref, tol=KTOL, what="groupnorm from partials")
     # launches that cannot produce partials say so instead of writing nothing (vector-ALU kernel for Cout <= 4)
     y2, st2 = ops.conv2d(d(x), ops.pack_conv_weight(d(w[:3].contiguous())), 3, 3, with_stats=True)
     assert st2 is None
@@ -423,7 +426,7 @@ def test_direct_conv_epilogue_groupnorm_partials(ksize, stride, cfg, B, H, W):
     sc, sh = ops.groupnorm_finalize(st, Ho * Wo, d(gamma), d(beta), G, eps)
     ref = F.group_norm(yc, G, gamma.double(), beta.double(), eps)
     got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
-    _close(got.float(), ref, tol=2e-5, what=f"groupnorm from direct-conv partials k{ksize} s{stride} cfg{cfg}")
+    _close(got.float(), ref, tol=KTOL, what=f"groupnorm from direct-conv partials k{ksize} s{stride} cfg{cfg}")
 
 
 def test_groupnorm_finalize_concat_and_large_mean():
@@ -443,7 +446,7 @@ def test_groupnorm_finalize_concat_and_large_mean():
     full = torch.cat([ya, yb], 1).cpu().double()
     ref = F.group_norm(full, G, gamma.double(), beta.double(), eps)
     got = full * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
-    _close(got.float(), ref, tol=2e-5, what="concat groupnorm from partials")
+    _close(got.float(), ref, tol=KTOL, what="concat groupnorm from partials")
     # identity filter + bias 100: output = 1e-2 * noise + 100
     C = 32
     x = _rand(1, C, 16, 16, seed=176) * 1e-2
@@ -477,7 +480,7 @@ def test_attention(N):
     B, C = 2, 256
     qkv = _rand(B, 3 * C, N, seed=40 + N) * 1.5
     got = ops.attention(qkv.to(DEV), 8)
-    _close(got, _attn_ref(qkv, C // 8), tol=2e-5, what=f"attention N={N}")
+    _close(got, _attn_ref(qkv, C // 8), tol=KTOL, what=f"attention N={N}")
 
 
 def test_attention_online_rescale_branch():
@@ -491,7 +494,7 @@ def test_attention_online_rescale_branch():
         got = ops.attention(qkv.to(DEV), 8)
         ref = _attn_ref(qkv, C // 8)
         assert torch.isfinite(got).all()
-        _close(got, ref, tol=5e-5, what=f"attention spike at key {spike_at}")
+        _close(got, ref, tol=KTOL, what=f"attention spike at key {spike_at}")
 
 
 def test_attention_rejects_other_head_dims():
@@ -556,18 +559,26 @@ def test_denorm_u8_bit_exact():
 
 
 def test_denorm_u8_three_reference_forms_bit_exact():
-    """The reference converts latents to uint8 in three places, each with its own fp32 operation order:
-    image_generator.py:441-447, generate_test.py:94-97 (bit-equal to the first) and diffusion_generator.py:231-232
-    (`(x+1)*127.5`, rounds differently).  Every form of the kernel equals its numpy/torch restatement bit for bit; the
-    inputs include every value that maps near an integer boundary of either scaling."""
+    """The reference converts latents to uint8 in three places, each spelled differently: image_generator.py:441-447
+    (clamp((x+1)/2) * 255), generate_test.py:94-97 ((clamp(x)+1) * 0.5 * 255) and diffusion_generator.py:231-232
+    (clip((x+1) * 127.5, 0, 255)).  Every form of the kernel equals its numpy/torch restatement bit for bit -- and all three
+    are bit-identical to each other: halving is exact in binary floating point, so (x+1)/2*255 and (x+1)*127.5 round the
+    SAME real number once (VERDICT r01 expected the third form to round differently; measured here on every boundary value
+    of both scalings +- a few ulps, it does not)."""
     from oracle import sampler as osampler
     from synt_isic_amd import ops
     g = torch.Generator().manual_seed(71)
     x = torch.randn(4, 3, 64, 64, generator=g) * 0.7
-    # values at and around k/127.5 - 1 (the boundaries of form 2) and k/255*2 - 1 (forms 0/1), k = 0..255, +- a few ulps
+    # values at and around k/127.5 - 1 and k/255*2 - 1 (the integer boundaries of either scaling), k = 0..255, +- ulps
     k = torch.arange(0, 256, dtype=torch.float64)
     edges = torch.cat([(k / 127.5 - 1).float(), (k / 255 * 2 - 1).float()])
-    ulps = torch.stack([torch.nextafter(edges, torch.full_like(edges, s)) for s in (-9.0, 9.0)] + [edges]).reshape(-1)
+    near = [edges]
+    for direction in (-9.0, 9.0):
+        e = edges.clone()
+        for _ in range(3):
+            e = torch.nextafter(e, torch.full_like(e, direction))
+            near.append(e.clone())
+    ulps = torch.cat(near)
     x.view(-1)[: ulps.numel()] = ulps
     x[3, 2, 5, :6] = torch.tensor([-1.5, -1.0, 1.0, 3.0, float("inf"), -float("inf")])
     xd = x.to(DEV)
@@ -577,8 +588,7 @@ def test_denorm_u8_three_reference_forms_bit_exact():
     assert np.array_equal(a, osampler.denormalize_to_uint8(x))
     assert np.array_equal(b, osampler.denormalize_to_uint8_generate_test(x))
     assert np.array_equal(c, osampler.denormalize_to_uint8_diffusion_generator(x))
-    assert np.array_equal(a, b)                                   # the two spellings agree on every input
-    assert (a != c).any() and np.abs(a.astype(int) - c.astype(int)).max() <= 1   # the third rounds differently, by <= 1 LSB
+    assert np.array_equal(a, b) and np.array_equal(a, c)          # the three spellings agree on every input
     assert np.array_equal(a, ops.denorm_u8(xd).cpu().numpy())    # default = image_generator.py's form
 
 
@@ -632,7 +642,7 @@ def test_conv2d_auto_dispatch_fuzz():
                            gn_silu=kw.get("gn_silu", False), chan_bias=d(kw.get("chan_bias")),
                            residual=d(kw.get("residual")), relu=kw["relu"], w_winograd=wino, with_stats=True)
         what = f"case {case}: k{k} s{stride} ups{int(ups)} B{B} {c0}+{c1}->{cout} @{H}x{W} wino={wino is not None}"
-        _close(y, ref, tol=3e-5, what=what)
+        _close(y, ref, tol=KTOL, what=what)
         picked.add((k, stride, ups, wino is not None, st is not None))
         if st is not None:
             stc, yc = st.cpu().double(), y.cpu().double()
