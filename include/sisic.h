@@ -176,6 +176,11 @@ const char* sisic_unet_tensor_name(const sisic_unet*, int index);
  * the given element counts; every expected tensor must be present exactly once.    */
 int sisic_unet_load(sisic_unet*, int n, const char* const* names, const float* const* host_ptrs,
                     const int64_t* numels);
+/* Latency mode (off by default): kernel choices that let ONE image fill the chip -- the reference generates its images one
+ * at a time (image_generator.py:379, batch 1) -- at the price of extra partial-sum traffic that costs throughput at large
+ * batches.  The choice depends on the layer shapes only, so results stay independent of the batch WITHIN a mode; between
+ * the two modes results differ in the last bits (different summation order over the input channels).                  */
+int sisic_unet_set_latency_mode(sisic_unet*, int on);
 /* eps = model(sample, timestep).sample.  timesteps: host int64 [B] (one per sample). */
 int sisic_unet_forward(sisic_unet*, const float* sample, const int64_t* timesteps,
                        float* out, int B, int H, int W, void* stream);
@@ -222,16 +227,17 @@ int sisic_mse_loss(sisic_unet*, const float* pred, const float* target, int64_t 
 int sisic_unet_backward(sisic_unet*, const float* dout, void* stream);
 int sisic_unet_zero_grad(sisic_unet*, void* stream);
 /* scaler.step(optimizer) (train_diffusion.py:232-233) with torch.optim.Adam's update: gradients are multiplied by inv_scale,
- * m/v/step advance, parameters move, and every packed form of the weights is rebuilt.  found_inf != NULL: the gradients are
+ * m/v/step advance, parameters move, and every packed form of the weights is rebuilt.  lr, betas and eps are doubles, as
+ * torch.optim.Adam holds them (1 - beta and lr / bias_correction are formed in double and rounded to fp32 once).  found_inf != NULL: the gradients are
  * first checked for inf/nan (one synchronisation); *found_inf = 1 skips the update like GradScaler.step does.           */
-int sisic_unet_optimizer_step(sisic_unet*, float lr, float beta1, float beta2, float eps, float inv_scale, int* found_inf,
+int sisic_unet_optimizer_step(sisic_unet*, double lr, double beta1, double beta2, double eps, float inv_scale, int* found_inf,
                               void* stream);
 /* The whole loop body (train_diffusion.py:215-233) on one stream: add_noise, forward, MSE, backward, optimizer step.
  * images / noise: dev [B,C,H,W]; timesteps and the two add_noise coefficient rows: HOST arrays [B].
  * loss_out (host, may be NULL) receives the unscaled loss (one synchronisation).                                       */
 int sisic_unet_train_step(sisic_unet*, const float* images, const float* noise, const int64_t* timesteps,
-                          const float* sqrt_alpha_prod, const float* sqrt_one_minus_alpha_prod, int B, int H, int W, float lr,
-                          float beta1, float beta2, float eps, float loss_scale, float* loss_out, int* found_inf, void* stream);
+                          const float* sqrt_alpha_prod, const float* sqrt_one_minus_alpha_prod, int B, int H, int W, double lr,
+                          double beta1, double beta2, double eps, float loss_scale, float* loss_out, int* found_inf, void* stream);
 /* Copy one tensor of the state dict (index as in sisic_unet_tensor_name) to the host: what = 0 parameter, 1 gradient,
  * 2 Adam first moment, 3 Adam second moment.  Synchronises the device.                                                  */
 int sisic_unet_read(sisic_unet*, int what, int index, float* host_out, int64_t numel);

@@ -99,6 +99,17 @@ inline int ensure_dynamic_lds(sisic_ctx* ctx, const void* kern, int bytes, std::
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// Latency mode (tile_cfg 78 / 79): ways the input channels of a Winograd convolution are split over workgroups so that ONE
+// image already offers ~256 workgroups.  A function of the layer shape only -- never of the batch -- so that an image's
+// bits do not depend on the batch it is computed in.
+inline int wino_latency_ksplit(int Cout, int Cin, int Hout, int Wout) {
+    const int co_t = Cout > 64 ? 128 : 64;
+    const int per_image = cdiv(Hout, 8) * cdiv(Wout, 16) * cdiv(Cout, co_t);
+    const int nchunks = cdiv(Cin, 8);
+    int k = 1;
+    while (per_image * k < 256 && k < 8 && nchunks % (2 * k) == 0) k *= 2;
+    return k;
+}
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

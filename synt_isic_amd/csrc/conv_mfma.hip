@@ -483,16 +483,27 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s, int* slots_query);
 
 // Winograd F(2x2,3x3) is taken for 3x3 stride-1 convolutions with transformed filters at hand: when forced by
-// tile_cfg 60..67 / 90, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
+// tile_cfg 60..69 / 78 / 79 / 90, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
 // there are 32-bit).  Returns the tile configuration, 0 = not Winograd.
 static int winograd_cfg(const sisic_conv_args& a) {
     if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4) || a.upsample == 2) return 0;
-    if ((a.tile_cfg >= 60 && a.tile_cfg <= 67) || a.tile_cfg == 90) return a.tile_cfg;
+    if ((a.tile_cfg >= 60 && a.tile_cfg <= 69) || a.tile_cfg == 78 || a.tile_cfg == 79 || a.tile_cfg == 90) return a.tile_cfg;
     if (a.tile_cfg != 0) return 0;
     const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
     const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
     if (!fits32) return 0;
-    if (Hout >= 12 && Wout >= 12) return 66;
+    if (Hout >= 12 && Wout >= 12) {
+        // second geometry (conv_winograd_wide.inc) unless SISIC_WINO_WIDE=0; nearest-2x inputs keep the nine-position form
+        static const bool wide_on = [] { const char* e = std::getenv("SISIC_WINO_WIDE"); return !e || std::atoi(e) != 0; }();
+        // measured per layer (tools/conv_bench.py, profiles/r02/conv_bench_geometries.txt): 128-channel tiles win 2-4 % on
+        // every Cout >= 128 layer; the 64-channel two-workgroups-per-CU form saves ~10 us of un-overlapped prologue /
+        // output-transform time per launch but runs 8 % longer per chunk, so it pays up to 8 chunks (Cin <= 64)
+        if (wide_on && !a.upsample) {
+            if (a.Cout > 64) return 68;
+            if (a.c0 + a.c1 <= 64) return 69;
+        }
+        return 66;
+    }
     // the 8x8 level (and the classifier's 7x7): four images per workgroup and the input channels split four ways
     // keep all CUs busy
     const int Cin = a.c0 + a.c1;
@@ -511,6 +522,8 @@ int conv_stats_slots(const sisic_conv_args& a) {
     if (const int cfg = winograd_cfg(a)) {
         if (cfg == 90) return 1;
         const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
+        if ((cfg == 78 || cfg == 79) && wino_latency_ksplit(a.Cout, a.c0 + a.c1, Hout, Wout) > 1) return 1;   // from the plane reduction
+        if (cfg == 68 || cfg == 69 || cfg == 78 || cfg == 79) return ((Hout + 7) / 8) * ((Wout + 15) / 16);   // 8 x 16 output pixels per workgroup
         const int edge = (cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 8 : 16;
         return ((Hout + edge - 1) / edge) * ((Wout + edge - 1) / edge);
     }
@@ -564,7 +577,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     const bool wino_ups9 = use_wino && a.upsample && !a.gn_scale && winograd_cfg(a) == 66;
     ProfileScope prof(slots_query ? nullptr : ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops,
                       use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops,
-                      (use_wino && !wino_ups9 && winograd_cfg(a) == 66) ? PK_WINO_MAIN : -1);
+                      (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || winograd_cfg(a) == 68 || winograd_cfg(a) == 69 || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
 
     if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50)) {
         if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)
@@ -576,7 +589,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         SISIC_REQUIRE(!slots_query, "conv2d: internal: slot query on the Winograd path");
         return launch_conv_winograd(ctx, a, a.w_winograd, winograd_cfg(a), s);
     }
-    SISIC_REQUIRE((cfg < 60 || cfg > 67) && cfg != 90, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
+    SISIC_REQUIRE((cfg < 60 || cfg > 69) && cfg != 78 && cfg != 79 && cfg != 90, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 2>(ctx, p, s);   // 2-channel chunks: 4 spill 256 B/lane (13 weight float4 + 15 halo elements per thread)

@@ -55,6 +55,7 @@ struct WinoParams {
     int Hc, Wc;         // conv extent (= output extent), after the optional 2x upsample
     int ups;
     const float* u;     // packed transformed filters [Cin_pad][16][cout_pad]
+    const float* uw;    // the same filters in the wide form's packing (conv_winograd_wide.inc), behind the first
     int cout_pad;
     const float* bias;
     int Cout;
@@ -757,16 +758,29 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int Cout, int 
     }
 }
 
+// two packings back to back: [Cin_pad][16][cout_pad] (first form) and [chunk][xi][32-ch block][lane][4] (wide form, its
+// channel blocks padded to whole 128-channel tiles)
+static int64_t winograd_first_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * conv_cout_pad(Cout); }
+static int64_t winograd_wide_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * round_up(Cout, 128); }
+__global__ void winograd_pack_wide_kernel(const float* __restrict__ u_first, int cin_pad, int cout_pad, int cout_pad128,
+                                          float* __restrict__ out);
+
 int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s) {
     const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout);
     const size_t total = (size_t)cin_pad * cout_pad;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(winograd_pack_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, cin_pad, cout_pad, packed);
+    const int cout_pad128 = round_up(Cout, 128);
+    const size_t total_w = (size_t)cin_pad * 16 * cout_pad128;
+    hipLaunchKernelGGL(winograd_pack_wide_kernel, dim3((unsigned)std::min<size_t>((total_w + 255) / 256, 4096)), dim3(256), 0, s,
+                       packed, cin_pad, cout_pad, cout_pad128, packed + winograd_first_numel(Cout, Cin));
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
 
-int64_t winograd_packed_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * conv_cout_pad(Cout); }
+int64_t winograd_packed_numel(int Cout, int Cin) { return winograd_first_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin); }
+
+#include "conv_winograd_wide.inc"
 
 // K-split reduction: out = sum_k part[k] + bias + per-sample channel bias + residual (+ReLU), and the GroupNorm partials
 // of the result.  One wave per (image, channel) plane of HW <= 256 pixels; the plane is the only statistics slot.
@@ -823,6 +837,49 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
+// K-split reduction for planes of any size (latency mode of the second geometry): one workgroup per (image, channel) plane;
+// the plane is the only statistics slot.  Fixed summation order over the K partial slabs and inside the block.
+__global__ void __launch_bounds__(256) splitk_reduce_plane_kernel(const float* __restrict__ part, int ksplit, int planes, int HW,
+                                                                  int Cout, const float* __restrict__ bias,
+                                                                  const float* __restrict__ chan_bias, int chan_bias_stride,
+                                                                  const float* __restrict__ residual, int relu,
+                                                                  float* __restrict__ out, float* __restrict__ stats) {
+    __shared__ float red[8];
+    const int plane = blockIdx.x;
+    const int b = plane / Cout, co = plane % Cout;
+    float add = bias ? bias[co] : 0.0f;
+    if (chan_bias) add += chan_bias[(size_t)b * chan_bias_stride + co];
+    const size_t base = (size_t)plane * HW, kstride = (size_t)planes * HW;
+    auto value = [&](int px) {
+        float acc = part[base + px];
+        for (int k = 1; k < ksplit; ++k) acc += part[base + px + k * kstride];
+        acc += add;
+        if (residual) acc += residual[base + px];
+        return relu ? fmaxf(acc, 0.0f) : acc;
+    };
+    const float K0 = value(0);                     // shift of the running sums: one of the plane's own values
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int px = threadIdx.x; px < HW; px += 256) {
+        const float v = value(px);
+        out[base + px] = v;
+        const float d = v - K0;
+        s1 += d;
+        s2 = fmaf(d, d, s2);
+    }
+    if (stats) {
+        s1 = wave64_sum(s1);
+        s2 = wave64_sum(s2);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t1 = (red[0] + red[1]) + (red[2] + red[3]), t2 = (red[4] + red[5]) + (red[6] + red[7]);
+            const float cnt = (float)HW;
+            reinterpret_cast<float4*>(stats)[plane] = make_float4(cnt, fmaf(cnt, K0, t1), fmaxf(t2 - t1 * t1 / cnt, 0.0f), 0.0f);
+        }
+    }
+}
+
 template <int NIMG, int TY, int TX, int PRO, int NW, bool UPS = false>
 static int launch_wino(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
     using G = WinoGeom<NIMG, TY, TX, NW, UPS>;
@@ -859,6 +916,9 @@ static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
 // tile_cfg 60: 1 image x 8x8 tiles (16x16 output pixels), 8 waves;  61: 4 images x 4x4 tiles (8x8 outputs each), 8 waves;
 //          62 / 63: the same two tilings with 16 waves (one transform position per wave, 4 waves per SIMD)
 //          64..67 = 60..63 with the MFMA-first / stage-first phase stagger between SIMD partner waves
+//          68 / 69: second geometry, 32 tiles per workgroup, filters straight from global memory into registers:
+//              68 = 128 output channels x 16 waves (Cout > 64), 69 = 64 channels x 8 waves, two workgroups per CU
+//          78 / 79: 68 / 69 in latency mode: input channels K-split so that one image fills the chip (wino_latency_ksplit)
 //          90: tiling 67 with the input channels split over four workgroups per tile + splitk_reduce_kernel -- for the
 //              8x8 level, where 64 tiles x 64 channels per workgroup leave 3/4 of the CUs without work
 int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s) {
@@ -877,6 +937,37 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
                   "conv2d(winograd): per-thread load offsets are 32-bit; this tensor needs the direct kernel");
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
+    if (cfg == 68 || cfg == 69 || cfg == 78 || cfg == 79) {           // second geometry (conv_winograd_wide.inc)
+        SISIC_REQUIRE(!p.ups, "conv2d(winograd wide): no upsample form");
+        p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1);
+        p.cout_pad = round_up(a.Cout, 128);
+        const bool wide = cfg == 68 || cfg == 78;
+        const int K = cfg >= 78 ? wino_latency_ksplit(a.Cout, a.c0 + a.c1, p.Hc, p.Wc) : 1;
+        if (K == 1) return wide ? launch_wide_pro<128, 16>(ctx, p, s) : launch_wide_pro<64, 8>(ctx, p, s);
+        // latency mode: the input channels split K ways over workgroups, partial slabs summed by the plane reduction
+        const size_t HW = (size_t)p.Hc * p.Wc, planes = (size_t)a.B * a.Cout;
+        const size_t need = (size_t)K * planes * HW;
+        float* scratch = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(ctx->splitk_mutex);
+            auto& buf = ctx->splitk[s];
+            if (buf.floats < need) {
+                SISIC_HIP(hipStreamSynchronize(s));
+                if (buf.p) SISIC_HIP(hipFree(buf.p));
+                buf.p = nullptr; buf.floats = 0;
+                SISIC_HIP(hipMalloc(reinterpret_cast<void**>(&buf.p), need * sizeof(float)));
+                buf.floats = need;
+            }
+            scratch = buf.p;
+        }
+        p.ksplit = K;
+        p.part = scratch;
+        SISIC_TRY(wide ? (launch_wide_pro<128, 16>(ctx, p, s)) : (launch_wide_pro<64, 8>(ctx, p, s)));
+        hipLaunchKernelGGL(splitk_reduce_plane_kernel, dim3((unsigned)planes), dim3(256), 0, s, scratch, K, (int)planes, (int)HW,
+                           a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu, a.out, a.stats_out);
+        SISIC_HIP(hipGetLastError());
+        return SISIC_OK;
+    }
     if (cfg == 90) {
         constexpr int K = 4;
         const size_t HW = (size_t)p.Hc * p.Wc, planes = (size_t)a.B * a.Cout;

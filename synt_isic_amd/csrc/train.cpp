@@ -379,7 +379,7 @@ int sisic_add_noise(sisic_ctx* ctx, const float* x0, const float* noise, const f
                             static_cast<hipStream_t>(stream));
 }
 
-int sisic_unet_optimizer_step(sisic_unet* u, float lr, float beta1, float beta2, float eps, float inv_scale, int* found_inf,
+int sisic_unet_optimizer_step(sisic_unet* u, double lr, double beta1, double beta2, double eps, float inv_scale, int* found_inf,
                               void* stream) {
     SISIC_TRY(require_train(u, "optimizer_step"));
     TrainState* tr = u->train.get();
@@ -404,8 +404,8 @@ int sisic_unet_optimizer_step(sisic_unet* u, float lr, float beta1, float beta2,
 }
 
 int sisic_unet_train_step(sisic_unet* u, const float* images, const float* noise, const int64_t* timesteps,
-                          const float* sqrt_alpha_prod, const float* sqrt_one_minus_alpha_prod, int B, int H, int W, float lr,
-                          float beta1, float beta2, float eps, float loss_scale, float* loss_out, int* found_inf,
+                          const float* sqrt_alpha_prod, const float* sqrt_one_minus_alpha_prod, int B, int H, int W, double lr,
+                          double beta1, double beta2, double eps, float loss_scale, float* loss_out, int* found_inf,
                           void* stream) {
     SISIC_TRY(require_train(u, "train_step"));
     SISIC_REQUIRE(images && noise && timesteps && sqrt_alpha_prod && sqrt_one_minus_alpha_prod, "train_step: null argument");

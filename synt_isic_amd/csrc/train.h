@@ -40,7 +40,7 @@ int launch_silu_bwd(sisic_ctx*, const float* dy, const float* pre, size_t n, flo
 int launch_mse(sisic_ctx*, const float* pred, const float* target, size_t n, float grad_scale, float* loss_dev, float* dpred,
                float* part, int nparts, hipStream_t s);
 int launch_check_finite(sisic_ctx*, const float* g, size_t n, int* flag, hipStream_t s);
-int launch_adam(sisic_ctx*, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+int launch_adam(sisic_ctx*, float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
                 int64_t step, float inv_scale, hipStream_t s);
 int launch_add_noise(sisic_ctx*, const float* x0, const float* noise, const float* a_dev, const float* c_dev, float* out, int B,
                      size_t per, hipStream_t s);

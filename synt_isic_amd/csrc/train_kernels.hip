@@ -664,11 +664,14 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
-int launch_adam(sisic_ctx*, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+int launch_adam(sisic_ctx*, float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps,
                 int64_t step, float inv_scale, hipStream_t s) {
-    const double bc1 = 1.0 - std::pow((double)b1, (double)step), bc2 = 1.0 - std::pow((double)b2, (double)step);
+    // the scalars as torch forms them: Python doubles (1 - beta, lr / bias_correction1, sqrt(bias_correction2)) rounded to
+    // fp32 once, when they meet the fp32 tensors
+    const double bc1 = 1.0 - std::pow(b1, (double)step), bc2 = 1.0 - std::pow(b2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, p, g, m, v, n,
-                       1.0f - b1, b2, 1.0f - b2, (float)((double)lr / bc1), (float)std::sqrt(bc2), eps, inv_scale);
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)std::sqrt(bc2), (float)eps,
+                       inv_scale);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

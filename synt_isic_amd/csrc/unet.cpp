@@ -356,6 +356,14 @@ struct Fwd {
         if (gn_prologue) { a.gn_scale = gsc; a.gn_shift = gsh; a.gn_silu = silu ? 1 : 0; }
         a.chan_bias = chan_bias; a.chan_bias_stride = tproj_stride;
         a.residual = residual; a.out = out;
+        if (u->latency_mode) {
+            // single-image latency (the reference's own call pattern, image_generator.py:379: batch 1): the Winograd
+            // convolutions split their input channels over workgroups (tile_cfg 78 / 79) and the 1x1 convolutions take the
+            // 64-pixel tiles, so that one image offers a few hundred workgroups per layer.  Chosen from the layer shape only:
+            // inside this mode an image's bits are again independent of the batch.
+            if (c.k == 3 && stride == 1 && !ups && a.w_winograd && c.cout > 4 && H >= 12 && W >= 12) a.tile_cfg = c.cout > 64 ? 78 : 79;
+            else if (c.k == 1 && stride == 1) a.tile_cfg = 22;
+        }
         if (normed_later && u->fuse_gn) {          // a GroupNorm reads this output: have the epilogue leave partials
             const int slots = conv_stats_slots(a);
             if (slots > 0) {
@@ -617,6 +625,12 @@ int sisic_unet_destroy(sisic_unet* u) {
     for (auto e : u->stage_ev)
         if (e) (void)hipEventDestroy(e);
     delete u;
+    return SISIC_OK;
+}
+
+int sisic_unet_set_latency_mode(sisic_unet* u, int on) {
+    SISIC_REQUIRE(u, "set_latency_mode: null handle");
+    u->latency_mode = on != 0;
     return SISIC_OK;
 }
 

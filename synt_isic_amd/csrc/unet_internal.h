@@ -174,6 +174,7 @@ struct sisic_unet {
     uint64_t stage_next = 0;
     hipEvent_t stage_ev[STAGE_SLOTS] = {};
     bool stage_used[STAGE_SLOTS] = {};
+    bool latency_mode = false;      // sisic_unet_set_latency_mode: per-layer kernels chosen so that ONE image fills the chip
     bool use_winograd = true;
     bool fuse_gn = true;            // GroupNorm statistics from convolution epilogues where the kernel offers them
                                     // (SISIC_FUSED_GN=0 in the environment: always the stand-alone statistics pass)

@@ -283,9 +283,12 @@ def apply_color_statistics(images: np.ndarray, stats: Optional[dict]) -> np.ndar
 class Sampler:
     """Holds one loaded UNet per class, like ``ModelManager.loaded_models`` (model_manager.py:19-171)."""
 
-    def __init__(self, device="cuda", beta_schedule: str = "squaredcos_cap_v2"):
+    def __init__(self, device="cuda", beta_schedule: str = "squaredcos_cap_v2", latency_mode: bool = False):
+        """latency_mode=True: every model of this sampler uses the single-image kernel choices
+        (HipUNet2DModel.set_latency_mode) -- for the GUI's one-image-at-a-time calls; throughput batches keep the default."""
         self.device = torch.device(device)
         self.beta_schedule = beta_schedule
+        self.latency_mode = bool(latency_mode)
         self.models: Dict[str, HipUNet2DModel] = {}
         self.cancel = C.c_int(0)          # cooperative stop flag (image_generator.py:320,396)
         self.noise_segment_steps = 64     # steps of noise drawn and uploaded per pipeline stage (NoiseStream)
@@ -305,6 +308,7 @@ class Sampler:
 
     def add_model(self, class_name: str, state_dict: Dict[str, torch.Tensor], **unet_kwargs) -> HipUNet2DModel:
         m = HipUNet2DModel(**unet_kwargs)
+        m.set_latency_mode(self.latency_mode)
         m.load_state_dict(state_dict)
         m = m.to(self.device)
         m.eval()

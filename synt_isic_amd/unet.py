@@ -87,6 +87,7 @@ class HipUNet2DModel:
         self.training = True                  # nn.Module default until .eval()
         self._train_begun = False             # gradient / Adam arenas exist in the library (HipAdam creates them)
         self._tape_input = None               # input of the last training-mode forward (the tape points into it)
+        self._latency_mode = False
         self._params_stale = False            # the library's weights have moved on (optimizer steps) since _params was read
 
     # ------------------------------------------------------------------ nn.Module surface
@@ -109,6 +110,15 @@ class HipUNet2DModel:
         return self
 
     def requires_grad_(self, flag: bool = True) -> "HipUNet2DModel":
+        return self
+
+    def set_latency_mode(self, on: bool = True) -> "HipUNet2DModel":
+        """Kernel choices for single-image latency (sisic_unet_set_latency_mode): the reference samples one image at a
+        time (image_generator.py:379).  Results are batch-independent within a mode and differ in the last bits between
+        modes, so a sampler should stay in one mode."""
+        self._latency_mode = bool(on)
+        if self._handle is not None:
+            check(_lib.load().sisic_unet_set_latency_mode(self._handle, int(self._latency_mode)))
         return self
 
     def _ensure_training(self) -> None:
@@ -223,6 +233,8 @@ class HipUNet2DModel:
         h = C.c_void_p()
         check(lib.sisic_unet_create(ops.context(self._device), C.byref(c), C.byref(h)))
         self._handle = h
+        if self._latency_mode:
+            check(lib.sisic_unet_set_latency_mode(h, 1))
         # the library's own view of the expected keys must agree with ours
         n = lib.sisic_unet_num_tensors(h)
         names = [lib.sisic_unet_tensor_name(h, i).decode() for i in range(n)]

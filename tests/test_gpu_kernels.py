@@ -172,6 +172,11 @@ def _run_wino(x, w, cfg, **kw):
                                        (61, 8, 8, 8), (61, 5, 8, 8), (61, 3, 6, 10), (0, 2, 32, 32), (0, 2, 8, 8),
                                        (62, 2, 16, 16), (62, 2, 64, 64), (62, 3, 18, 10), (62, 2, 9, 23), (63, 8, 8, 8),
                                        (63, 5, 8, 8), (63, 3, 6, 10), (66, 2, 16, 16), (66, 3, 18, 10), (67, 5, 8, 8),
+                                       # second geometry: 68 = 128 channels x 32 tiles, 69 = 64 channels x 32 tiles (2 WG / CU)
+                                       (68, 2, 16, 16), (68, 2, 64, 64), (68, 1, 32, 48), (68, 3, 18, 10), (68, 2, 9, 23),
+                                       (69, 2, 16, 16), (69, 2, 64, 64), (69, 1, 32, 48), (69, 3, 18, 10), (69, 2, 9, 23),
+                                       # latency mode: the same geometry with the input channels K-split over workgroups
+                                       (78, 2, 16, 16), (78, 1, 32, 48), (78, 2, 9, 23), (79, 2, 16, 16), (79, 1, 64, 64),
                                        ])
 def test_conv3x3_winograd(cfg, B, H, W):
     """Winograd F(2x2,3x3) on the MFMA pipe == the float64 convolution, plain and with every fused feature
@@ -254,8 +259,13 @@ def test_conv3x3_winograd_reference_layers_and_identity():
         xx = _rand(1, cin, r, r, seed=130 + i)
         ww = _rand(cout, cin, 3, 3, seed=140 + i, scale=(cin * 9) ** -0.5)
         bb = _rand(cout, seed=150 + i, scale=0.1)
-        for cfg in (60, 62):
-            _close(_run_wino(xx, ww, cfg, bias=bb), _conv_ref(xx, ww, bb), what=f"winograd{cfg} layer {cin}->{cout}@{r}")
+        outs = {}
+        for cfg in (60, 62, 66, 68, 69):
+            outs[cfg] = _run_wino(xx, ww, cfg, bias=bb)
+            _close(outs[cfg], _conv_ref(xx, ww, bb), what=f"winograd{cfg} layer {cin}->{cout}@{r}")
+        # the second geometry (filters from global memory into registers, 32 tiles per workgroup) performs the same fp32
+        # operations in the same order as the first: identical bits
+        assert torch.equal(outs[68], outs[66]) and torch.equal(outs[69], outs[66])
     from synt_isic_amd import ops
     from synt_isic_amd._lib import SisicError
     with pytest.raises(SisicError, match="w_winograd"):
@@ -367,7 +377,9 @@ def test_groupnorm_large_mean_is_stable():
 
 @pytest.mark.parametrize("cfg,B,H,W,ups", [(66, 3, 32, 32, False), (62, 2, 18, 10, False), (60, 2, 9, 23, False),
                                            (64, 2, 16, 16, True), (61, 5, 8, 8, False), (67, 3, 6, 10, False),
-                                           (0, 2, 64, 64, False)])
+                                           (0, 2, 64, 64, False), (68, 3, 32, 32, False), (68, 2, 18, 10, False),
+                                           (69, 2, 9, 23, False), (69, 2, 32, 48, False), (78, 2, 16, 16, False),
+                                           (79, 2, 18, 10, False)])
 def test_conv_epilogue_groupnorm_partials(cfg, B, H, W, ups):
     """sisic_conv_args.stats_out: the Winograd output transform leaves (count, sum, centred M2) per image, channel and
     workgroup tile; sisic_groupnorm_finalize on them == sisic_groupnorm_stats on the stored tensor."""

@@ -151,3 +151,29 @@ def test_groupnorm_from_conv_epilogues_matches_standalone_pass(model, synthetic_
         x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)).to(DEV)
         a, b = model(x, t).sample, plain(x, t).sample
         assert (a - b).abs().max().item() <= 2e-5
+
+
+def test_latency_mode(synthetic_sd, golden_dir):
+    """sisic_unet_set_latency_mode: the single-image kernel choices (input channels of the Winograd convolutions K-split
+    over workgroups, 64-pixel 1x1 tiles).  Same tolerance against the goldens as the default mode, batch-independent and
+    deterministic within the mode, and within rounding of the default mode's result."""
+    from synt_isic_amd.unet import HipUNet2DModel
+    m = HipUNet2DModel().set_latency_mode(True)
+    m.load_state_dict(synthetic_sd)
+    m = m.to(DEV).eval()
+    g = np.load(os.path.join(golden_dir, "unet_forward_b1_128.npz"))
+    x128 = torch.from_numpy(g["x"]).to(DEV)
+    y = m(x128, int(g["t"])).sample
+    assert np.abs(y.cpu().numpy() - g["y"]).max() <= FWD_TOL
+    assert torch.equal(y, m(x128, int(g["t"])).sample)
+    xb = torch.cat([torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(3)).to(DEV), x128])
+    assert torch.equal(m(xb, int(g["t"])).sample[2], y[0])                 # an image's bits do not depend on its batch
+    g64 = np.load(os.path.join(golden_dir, "unet_forward_b2_64.npz"))
+    y64 = m(torch.from_numpy(g64["x"]).to(DEV), torch.from_numpy(g64["t"]).to(DEV)).sample
+    assert np.abs(y64.cpu().numpy() - g64["y"]).max() <= FWD_TOL
+    d = HipUNet2DModel()
+    d.load_state_dict(synthetic_sd)
+    d = d.to(DEV).eval()
+    assert (d(x128, int(g["t"])).sample - y).abs().max().item() <= 2e-5     # the two modes differ by rounding only
+    m.set_latency_mode(False)
+    assert torch.equal(m(x128, int(g["t"])).sample, d(x128, int(g["t"])).sample)

@@ -15,8 +15,10 @@ from synt_isic_amd.weights import synthetic_unet_state_dict  # noqa: E402
 
 
 def main():
-    s = Sampler()
+  for latency in (False, True):
+    s = Sampler(latency_mode=latency)
     s.add_model("NV", synthetic_unet_state_dict())
+    print(f"--- latency_mode={latency}", flush=True)
     for size in (64, 128):
         for B in (1, 4):
             s.generate_seeds("NV", list(range(B)), 8, (size, size))
