@@ -15,7 +15,7 @@ full run, for smaller K it is the per-step time extrapolated to 1000 steps (all 
 kernels).
 
 Besides the driver's fields the JSON line carries
-  roofline      the dominant kernel (conv_winograd_kernel<1,8,8,*,16>, 30 launches per step): FLOPs the matrix pipe
+  roofline      the dominant kernel family (the stride-1 Winograd F(2x2,3x3) convolutions, 31 launches per step): FLOPs the matrix pipe
                 EXECUTES per launch (Winograd F(2x2,3x3): 16/36 of the direct form) / average launch duration measured
                 with HIP events on the launch stream, vs the fp32 MFMA peak (157.3 TFLOP/s) -- frac <= 1 by construction;
                 the direct-form ("algorithmic") rate and the whole conv3x3 class are reported beside it
@@ -238,14 +238,16 @@ def main():
         # the committed counter passes of this same command (tools/prof_pmc.sh + tools/make_pmc_summary.py); the newest
         # round's summary that exists is used and named in traffic_source.
         traffic, traffic_src, traffic_class = None, None, None
-        dom_names = ("sisic::conv_winograd_kernel<1, 8, 8, 2, 16, false>",)
         for rnd in ("r02", "r01"):
             path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
             try:
                 with open(path) as f:
                     js = json.load(f)
-                e = js[dom_names[0]]
-                traffic = (e["hbm_read_MB_per_launch_corrected"] + e["hbm_write_MB_per_launch"]) * 1e6
+                if "_winograd_main" in js:
+                    traffic = js["_winograd_main"]["hbm_MB_per_launch"] * 1e6
+                else:
+                    e = js["sisic::conv_winograd_kernel<1, 8, 8, 2, 16, false>"]
+                    traffic = (e["hbm_read_MB_per_launch_corrected"] + e["hbm_write_MB_per_launch"]) * 1e6
                 traffic_class = js["_conv3x3_all"]["hbm_MB_per_launch"] * 1e6
                 traffic_src = (f"profiles/{rnd}/pmc_summary.json (committed rocprofv3 --pmc passes of `bench.py --steps 2 "
                                f"--warmup 1`, FETCH_SIZE doubled per MI355X_MICROARCH.md; not measured in this run)")
@@ -253,8 +255,9 @@ def main():
             except (OSError, KeyError, ValueError):
                 continue
         roofline = {
-            "kernel": "conv_winograd_kernel<1,8,8,PRO,16,false>: stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) on "
-                      "v_mfma_f32_32x32x2_f32 (GroupNorm+SiLU prologue, bias/temb/residual + GroupNorm partials epilogue)",
+            "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (GroupNorm+SiLU prologue, "
+                      "bias/temb/residual + GroupNorm partials epilogue): conv_winograd_wide_kernel<128,16> (Cout > 64), "
+                      "conv_winograd_wide_kernel<64,8> (Cin, Cout <= 64), conv_winograd_kernel<1,8,8,PRO,16,false> (Cout <= 64 < Cin)",
             "bound": "mfma",
             "achieved": d_exec,
             "peak": PEAK_FP32_MFMA_TFLOPS,

@@ -181,6 +181,10 @@ int sisic_unet_load(sisic_unet*, int n, const char* const* names, const float* c
  * batches.  The choice depends on the layer shapes only, so results stay independent of the batch WITHIN a mode; between
  * the two modes results differ in the last bits (different summation order over the input channels).                  */
 int sisic_unet_set_latency_mode(sisic_unet*, int on);
+/* sisic_sample as one captured step (hipGraph) replayed T-1 times instead of ~190 launches per step from the host:
+ * mode 1 on, 0 off, -1 (default) on exactly when latency mode is on.  Same kernels, same arithmetic, same bits; the
+ * loop then runs on a library-owned copy of x (written back at the end) so that every address in the graph is stable.   */
+int sisic_unet_set_graph_mode(sisic_unet*, int mode);
 /* eps = model(sample, timestep).sample.  timesteps: host int64 [B] (one per sample). */
 int sisic_unet_forward(sisic_unet*, const float* sample, const int64_t* timesteps,
                        float* out, int B, int H, int W, void* stream);

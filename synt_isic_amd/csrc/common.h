@@ -71,6 +71,8 @@ struct sisic_ctx {
     struct SplitK { float* p = nullptr; size_t floats = 0; };
     std::map<hipStream_t, SplitK> splitk;
     std::mutex splitk_mutex;
+    std::atomic<uint64_t> scratch_generation{0};    // bumped whenever a scratch buffer is re-allocated: captured graphs that
+                                                    // may hold its old address are rebuilt
 };
 
 namespace sisic {
@@ -110,6 +112,8 @@ inline int wino_latency_ksplit(int Cout, int Cin, int Hout, int Wout) {
     while (per_image * k < 256 && k < 8 && nchunks % (2 * k) == 0) k *= 2;
     return k;
 }
+// segments a plane is cut into by the K-split plane reduction (one workgroup and one statistics slot each): 1024 pixels
+inline int wino_latency_segments(int Hout, int Wout) { return cdiv(Hout * Wout, 1024); }
 inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
@@ -150,6 +154,12 @@ int launch_gn_stats(sisic_ctx*, const float* in0, int c0, const float* in1, int 
 int launch_attention(sisic_ctx*, const float* qkv, float* out, int B, int C, int N, int head_dim, hipStream_t s);
 int launch_ddpm_step(sisic_ctx*, const float* eps, const float* x, const float* z, float* out, int64_t n,
                      float sb, float sa, float c0, float c1, float sigma, float clip, hipStream_t s);
+// graph-replayed sampling loop (elementwise.hip): per-step parameters selected on the device by a step index
+size_t loop_state_bytes();     // {int step; int pad; const float* noise_base}
+int launch_loop_select_row(sisic_ctx*, const float* table, int R, const void* state, float* out, hipStream_t s);
+int launch_loop_advance(sisic_ctx*, void* state, hipStream_t s);
+int launch_ddpm_step_indexed(sisic_ctx*, const float* eps, float* x, int64_t n, const void* state, const float* coef,
+                             const int* zrow, float clip, hipStream_t s);
 int launch_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, hipStream_t s, int form = 0);
 // time embedding: sinusoid -> linear1 -> SiLU -> linear2 -> SiLU  (weights transposed [in][out])
 // save_* (optional, training): the sinusoid [B, 2 n_freqs] and the two linear outputs before their SiLU [B, hidden]

@@ -522,7 +522,7 @@ int conv_stats_slots(const sisic_conv_args& a) {
     if (const int cfg = winograd_cfg(a)) {
         if (cfg == 90) return 1;
         const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
-        if ((cfg == 78 || cfg == 79) && wino_latency_ksplit(a.Cout, a.c0 + a.c1, Hout, Wout) > 1) return 1;   // from the plane reduction
+        if ((cfg == 78 || cfg == 79) && wino_latency_ksplit(a.Cout, a.c0 + a.c1, Hout, Wout) > 1) return wino_latency_segments(Hout, Wout);   // from the plane reduction
         if (cfg == 68 || cfg == 69 || cfg == 78 || cfg == 79) return ((Hout + 7) / 8) * ((Wout + 15) / 16);   // 8 x 16 output pixels per workgroup
         const int edge = (cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 8 : 16;
         return ((Hout + edge - 1) / edge) * ((Wout + edge - 1) / edge);

@@ -837,19 +837,21 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     }
 }
 
-// K-split reduction for planes of any size (latency mode of the second geometry): one workgroup per (image, channel) plane;
-// the plane is the only statistics slot.  Fixed summation order over the K partial slabs and inside the block.
+// K-split reduction for planes of any size (latency mode of the second geometry): one workgroup per 1024-pixel segment of
+// an (image, channel) plane; every segment is one statistics slot.  Fixed summation order over the K partial slabs and
+// inside the block.
 __global__ void __launch_bounds__(256) splitk_reduce_plane_kernel(const float* __restrict__ part, int ksplit, int planes, int HW,
-                                                                  int Cout, const float* __restrict__ bias,
+                                                                  int segs, int Cout, const float* __restrict__ bias,
                                                                   const float* __restrict__ chan_bias, int chan_bias_stride,
                                                                   const float* __restrict__ residual, int relu,
                                                                   float* __restrict__ out, float* __restrict__ stats) {
     __shared__ float red[8];
-    const int plane = blockIdx.x;
+    const int plane = blockIdx.x / segs, seg = blockIdx.x % segs;
     const int b = plane / Cout, co = plane % Cout;
     float add = bias ? bias[co] : 0.0f;
     if (chan_bias) add += chan_bias[(size_t)b * chan_bias_stride + co];
     const size_t base = (size_t)plane * HW, kstride = (size_t)planes * HW;
+    const int p0 = seg * 1024, p1 = min(HW, p0 + 1024);
     auto value = [&](int px) {
         float acc = part[base + px];
         for (int k = 1; k < ksplit; ++k) acc += part[base + px + k * kstride];
@@ -857,14 +859,18 @@ __global__ void __launch_bounds__(256) splitk_reduce_plane_kernel(const float* _
         if (residual) acc += residual[base + px];
         return relu ? fmaxf(acc, 0.0f) : acc;
     };
-    const float K0 = value(0);                     // shift of the running sums: one of the plane's own values
+    const float K0 = value(p0);                    // shift of the running sums: one of the segment's own values
     float s1 = 0.0f, s2 = 0.0f;
-    for (int px = threadIdx.x; px < HW; px += 256) {
-        const float v = value(px);
-        out[base + px] = v;
-        const float d = v - K0;
-        s1 += d;
-        s2 = fmaf(d, d, s2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = p0 + threadIdx.x + 256 * i;
+        if (px < p1) {
+            const float v = value(px);
+            out[base + px] = v;
+            const float d = v - K0;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
     }
     if (stats) {
         s1 = wave64_sum(s1);
@@ -874,8 +880,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_plane_kernel(const float* _
         __syncthreads();
         if (threadIdx.x == 0) {
             const float t1 = (red[0] + red[1]) + (red[2] + red[3]), t2 = (red[4] + red[5]) + (red[6] + red[7]);
-            const float cnt = (float)HW;
-            reinterpret_cast<float4*>(stats)[plane] = make_float4(cnt, fmaf(cnt, K0, t1), fmaxf(t2 - t1 * t1 / cnt, 0.0f), 0.0f);
+            const float cnt = (float)(p1 - p0);
+            reinterpret_cast<float4*>(stats)[(size_t)plane * segs + seg] =
+                make_float4(cnt, fmaf(cnt, K0, t1), fmaxf(t2 - t1 * t1 / cnt, 0.0f), 0.0f);
         }
     }
 }
@@ -957,14 +964,16 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
                 buf.p = nullptr; buf.floats = 0;
                 SISIC_HIP(hipMalloc(reinterpret_cast<void**>(&buf.p), need * sizeof(float)));
                 buf.floats = need;
+                ctx->scratch_generation.fetch_add(1);
             }
             scratch = buf.p;
         }
         p.ksplit = K;
         p.part = scratch;
         SISIC_TRY(wide ? (launch_wide_pro<128, 16>(ctx, p, s)) : (launch_wide_pro<64, 8>(ctx, p, s)));
-        hipLaunchKernelGGL(splitk_reduce_plane_kernel, dim3((unsigned)planes), dim3(256), 0, s, scratch, K, (int)planes, (int)HW,
-                           a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu, a.out, a.stats_out);
+        const int segs = wino_latency_segments(p.Hc, p.Wc);
+        hipLaunchKernelGGL(splitk_reduce_plane_kernel, dim3((unsigned)(planes * segs)), dim3(256), 0, s, scratch, K, (int)planes,
+                           (int)HW, segs, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu, a.out, a.stats_out);
         SISIC_HIP(hipGetLastError());
         return SISIC_OK;
     }
@@ -984,6 +993,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
                 buf.p = nullptr; buf.floats = 0;
                 SISIC_HIP(hipMalloc(reinterpret_cast<void**>(&buf.p), need * sizeof(float)));
                 buf.floats = need;
+                ctx->scratch_generation.fetch_add(1);
             }
             scratch = buf.p;
         }

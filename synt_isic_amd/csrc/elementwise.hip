@@ -71,6 +71,88 @@ int launch_ddpm_step(sisic_ctx* ctx, const float* eps, const float* x, const flo
     return SISIC_OK;
 }
 
+// ---- the same step with its per-step parameters read from device memory (graph-replayed sampling loop) ----------------
+// One captured step is replayed for every step of the loop, so nothing that changes from step to step may be a launch
+// argument: the loop keeps {step index, noise base pointer} and its per-step tables (coefficients, noise row of the step
+// or -1) in device memory; this kernel selects its row, ddpm_advance_kernel moves the index on.
+struct LoopState {
+    int step;
+    int pad;
+    const float* noise;       // base of the [n_noise, n] noise rows of this call
+};
+
+__global__ void __launch_bounds__(256)
+ddpm_step_indexed_kernel(const float* __restrict__ eps, float* x, int64_t n, const LoopState* __restrict__ st,
+                         const float* __restrict__ coef, const int* __restrict__ zrow, float clip, int vec4) {
+    const int step = st->step;
+    const float sb = coef[5 * step + 0], sa = coef[5 * step + 1], c0 = coef[5 * step + 2], c1 = coef[5 * step + 3],
+                sigma = coef[5 * step + 4];
+    const int zr = zrow[step];
+    const float* z = zr >= 0 ? st->noise + (int64_t)zr * n : nullptr;
+    const bool noise = (z != nullptr) && (sigma != 0.0f);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec4 && ((reinterpret_cast<uintptr_t>(z) & 15) == 0)) {
+        const int64_t n4 = n >> 2;
+        const float4* e4 = reinterpret_cast<const float4*>(eps);
+        float4* x4 = reinterpret_cast<float4*>(x);
+        const float4* z4 = reinterpret_cast<const float4*>(z);
+        for (int64_t i = t0; i < n4; i += stride) {
+            const float4 e = e4[i], xv = x4[i];
+            float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (noise) zv = z4[i];
+            float4 r;
+            r.x = ddpm_one(e.x, xv.x, zv.x, sb, sa, c0, c1, sigma, clip, noise);
+            r.y = ddpm_one(e.y, xv.y, zv.y, sb, sa, c0, c1, sigma, clip, noise);
+            r.z = ddpm_one(e.z, xv.z, zv.z, sb, sa, c0, c1, sigma, clip, noise);
+            r.w = ddpm_one(e.w, xv.w, zv.w, sb, sa, c0, c1, sigma, clip, noise);
+            x4[i] = r;
+        }
+        for (int64_t i = (n4 << 2) + t0; i < n; i += stride)
+            x[i] = ddpm_one(eps[i], x[i], noise ? z[i] : 0.f, sb, sa, c0, c1, sigma, clip, noise);
+    } else {
+        for (int64_t i = t0; i < n; i += stride)
+            x[i] = ddpm_one(eps[i], x[i], noise ? z[i] : 0.f, sb, sa, c0, c1, sigma, clip, noise);
+    }
+}
+
+// tproj_cur[r] = tproj_table[step][r]: the time-embedding projections of the step about to run
+__global__ void loop_select_row_kernel(const float* __restrict__ table, int R, const LoopState* __restrict__ st,
+                                       float* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R) out[r] = table[(size_t)st->step * R + r];
+}
+
+__global__ void loop_advance_kernel(LoopState* st) { st->step += 1; }
+
+int launch_loop_select_row(sisic_ctx*, const float* table, int R, const void* state, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(loop_select_row_kernel, dim3(cdiv(R, 256)), dim3(256), 0, s, table, R, static_cast<const LoopState*>(state), out);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+int launch_loop_advance(sisic_ctx*, void* state, hipStream_t s) {
+    hipLaunchKernelGGL(loop_advance_kernel, dim3(1), dim3(1), 0, s, static_cast<LoopState*>(state));
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+int launch_ddpm_step_indexed(sisic_ctx* ctx, const float* eps, float* x, int64_t n, const void* state, const float* coef,
+                             const int* zrow, float clip, hipStream_t s) {
+    SISIC_REQUIRE(eps && x && state && coef && zrow && n > 0, "ddpm_step_indexed: null argument");
+    ProfileScope prof(ctx, s, PK_DDPM, 16.0 * (double)n, 0.0);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(eps) | reinterpret_cast<uintptr_t>(x);
+    const int vec4 = (al & 15) == 0 && (n & 3) == 0;
+    const int64_t work = vec4 ? (n + 3) / 4 : n;
+    const int blocks = (int)std::min<int64_t>((work + 255) / 256, 2048);
+    hipLaunchKernelGGL(ddpm_step_indexed_kernel, dim3(blocks), dim3(256), 0, s, eps, x, n, static_cast<const LoopState*>(state), coef,
+                       zrow, clip, vec4);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+size_t loop_state_bytes() { return sizeof(LoopState); }
+
 // ---- de-normalise to uint8 HWC ---------------------------------------------------------------
 // FORM 0: image_generator.py:441-447     clamp((x + 1) / 2, 0, 1) * 255, truncated
 // FORM 1: generate_test.py:94-97          (clamp(x, -1, 1) + 1) * 0.5 * 255, truncated   (bit-equal to form 0)

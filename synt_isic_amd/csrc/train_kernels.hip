@@ -100,6 +100,23 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     const float* a_base = aL + (nt * 32 + l31) * G::CHS + half * STRIDE;
     const float* d_base = dL + (mt * 32 + l31) * G::DYS + half;
 
+    // ---- staging plans, invariant over the pixel blocks (no division inside the block loop)
+    // dy tile: a thread keeps one pixel of the block (lane -> pixel when P = 64) and walks the output channels
+    static_assert(256 % G::P == 0 || G::P % 256 == 0, "dy staging plan");
+    constexpr int DY_CO_STEP = (G::P <= 256) ? 256 / G::P : 1;          // channels covered per pass
+    constexpr int DY_PASSES = (64 * G::P) / 256;
+    const int dpx = tid % G::P, dco = tid / G::P;                       // P >= 256 is not instantiated (P is 32 or 64)
+    const int dty = dpx / TC, dtx = dpx % TC;
+    // halo: wave w stages channels w*16 .. w*16+15; lanes sweep the HEL elements of a channel in HPASS passes
+    constexpr int HPASS = (G::HEL + 63) / 64;
+    int hyy[HPASS], hxx[HPASS];
+#pragma unroll
+    for (int q = 0; q < HPASS; ++q) {
+        const int r = min(lane + 64 * q, G::HEL - 1);
+        hyy[q] = r / G::IW;
+        hxx[q] = r % G::IW;
+    }
+
     for (int blk = blk_lo; blk < blk_hi; ++blk) {
         int t = blk;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
@@ -108,31 +125,58 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
         const int oy0 = ty * TR, ox0 = tx * TC;
         __syncthreads();                          // the previous block's fragments have been read
         // ---- dy tile: 64 channels x P pixels, zero outside the image / past Cout
-        for (int i = tid; i < 64 * G::P; i += 256) {
-            const int co = i / G::P, px = i % G::P;
-            const int oy = oy0 + px / TC, ox = ox0 + px % TC;
-            const bool ok = (co0 + co) < p.Cout && oy < p.Hout && ox < p.Wout;
-            const size_t src = ((size_t)b * p.Cout + min(co0 + co, p.Cout - 1)) * HWout + (size_t)min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
-            const float v = p.dy[src];
-            dL[co * G::DYS + px] = ok ? v : 0.0f;
+        {
+            const int oy = oy0 + dty, ox = ox0 + dtx;
+            const bool pin = oy < p.Hout && ox < p.Wout;
+            const float* src = p.dy + (size_t)b * p.Cout * HWout + (size_t)min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
+            float v[DY_PASSES];
+#pragma unroll
+            for (int k = 0; k < DY_PASSES; ++k) {
+                const int co = dco + k * DY_CO_STEP;
+                v[k] = src[(size_t)min(co0 + co, p.Cout - 1) * HWout];
+            }
+#pragma unroll
+            for (int k = 0; k < DY_PASSES; ++k) {
+                const int co = dco + k * DY_CO_STEP;
+                dL[co * G::DYS + dpx] = (pin && (co0 + co) < p.Cout) ? v[k] : 0.0f;
+            }
         }
         // ---- input halo: 64 channels x IH x IW with the forward's prologue, zero padding AFTER it
-        const int iy0 = oy0 * STRIDE - G::PAD, ix0 = ox0 * STRIDE - G::PAD;
-        for (int i = tid; i < 64 * G::HEL; i += 256) {
-            const int ci = i / G::HEL, r = i % G::HEL;
-            const int y = iy0 + r / G::IW, x = ix0 + r % G::IW;
-            const int c = ci0 + ci;
-            const bool ok = c < Cin && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
-            const int cc = min(c, Cin - 1);
-            const int ys = min(max(y, 0), p.Hc - 1) >> p.ups, xs = min(max(x, 0), p.Wc - 1) >> p.ups;
-            const float* plane = cc < p.c0 ? p.in0 + ((size_t)b * p.c0 + cc) * HWin
-                                           : p.in1 + ((size_t)b * p.c1 + (cc - p.c0)) * HWin;
-            float v = plane[ys * p.Win + xs];
-            if (p.gn_scale) {
-                v = v * p.gn_scale[(size_t)b * Cin + cc] + p.gn_shift[(size_t)b * Cin + cc];
-                if (p.gn_silu) v = silu_fwd(v);
+        {
+            const int iy0 = oy0 * STRIDE - G::PAD, ix0 = ox0 * STRIDE - G::PAD;
+            int goff[HPASS];
+            bool gok[HPASS];
+#pragma unroll
+            for (int q = 0; q < HPASS; ++q) {
+                const int y = iy0 + hyy[q], x = ix0 + hxx[q];
+                gok[q] = (lane + 64 * q) < G::HEL && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
+                goff[q] = (min(max(y, 0), p.Hc - 1) >> p.ups) * p.Win + (min(max(x, 0), p.Wc - 1) >> p.ups);
             }
-            aL[ci * G::CHS + r] = ok ? v : 0.0f;
+#pragma unroll 4
+            for (int j = 0; j < 16; ++j) {
+                const int ci = wave * 16 + j;
+                const int c = ci0 + ci;
+                const int cc = min(c, Cin - 1);
+                const float* plane = cc < p.c0 ? p.in0 + ((size_t)b * p.c0 + cc) * HWin
+                                               : p.in1 + ((size_t)b * p.c1 + (cc - p.c0)) * HWin;
+                float sc = 1.0f, sh = 0.0f;
+                if (p.gn_scale) {
+                    sc = p.gn_scale[(size_t)b * Cin + cc];
+                    sh = p.gn_shift[(size_t)b * Cin + cc];
+                }
+                float hv[HPASS];
+#pragma unroll
+                for (int q = 0; q < HPASS; ++q) hv[q] = plane[goff[q]];
+#pragma unroll
+                for (int q = 0; q < HPASS; ++q) {
+                    float v = hv[q];
+                    if (p.gn_scale) {
+                        v = v * sc + sh;
+                        if (p.gn_silu) v = silu_fwd(v);
+                    }
+                    if ((lane + 64 * q) < G::HEL) aL[ci * G::CHS + lane + 64 * q] = (gok[q] && c < Cin) ? v : 0.0f;
+                }
+            }
         }
         __syncthreads();
         // ---- P/2 k-steps x KK taps
@@ -190,7 +234,7 @@ static int wgrad_ksplit(const WgradArgs& a, int Hout, int Wout) {
     // enough workgroups for 256 CUs x 2: the weight tile count shrinks as the image grows and vice versa
     const int tiles = cdiv(a.Cout, 64) * cdiv(a.c0 + a.c1, 64);
     const int nblocks_min = a.B * cdiv(Hout, 8) * cdiv(Wout, 8);           // 64-pixel blocks
-    return std::max(1, std::min(nblocks_min, cdiv(768, tiles)));
+    return std::max(1, std::min(nblocks_min, cdiv(512, tiles)));       // two workgroups per CU
 }
 
 static void wgrad_out_dims(const WgradArgs& a, int* Hout, int* Wout) {
@@ -279,6 +323,30 @@ __global__ void __launch_bounds__(256) plane_sum_kernel(const float* __restrict_
 
 int launch_plane_sums(sisic_ctx*, const float* x, int planes, int HW, float* out, hipStream_t s) {
     hipLaunchKernelGGL(plane_sum_kernel, dim3(cdiv(planes, 4)), dim3(256), 0, s, x, planes, HW, out);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// Bias gradient and per-sample plane sums in one pass over dy: S[b,c] = sum_hw dy[b,c,:], db[c] = sum_b S[b,c].
+// One workgroup per channel, fixed order.
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ dy, int B, int C, int HW, float* __restrict__ S,
+                                                        float* __restrict__ db) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float total = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* src = dy + ((size_t)b * C + c) * HW;
+        float s = 0.0f;
+        for (int i = threadIdx.x; i < HW; i += 256) s += src[i];
+        s = block_sum_256(s, red);
+        if (threadIdx.x == 0) S[(size_t)b * C + c] = s;
+        total += s;
+    }
+    if (threadIdx.x == 0 && db) db[c] = total;
+}
+
+int launch_bias_grad(sisic_ctx*, const float* dy, int B, int C, int HW, float* S, float* db, hipStream_t s) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, s, dy, B, C, HW, S, db);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

@@ -225,7 +225,14 @@ void reset_derived(sisic_unet* u) {
 }
 
 // ------------------------------------------------------------------ workspace
+void loop_graph_drop(sisic_unet* u) {
+    if (u->loop_exec) (void)hipGraphExecDestroy(u->loop_exec);
+    if (u->loop_graph) (void)hipGraphDestroy(u->loop_graph);
+    u->loop_exec = nullptr; u->loop_graph = nullptr; u->loop_valid = false;
+}
+
 void pool_release_all(sisic_unet* u) {
+    loop_graph_drop(u);                 // a captured step holds addresses of pool blocks
     for (auto& b : u->pool) (void)hipFree(b.p);
     u->pool.clear();
 }
@@ -606,6 +613,7 @@ int sisic_unet_create(sisic_ctx* ctx, const sisic_unet_config* cfg, sisic_unet**
     u->freqs.assign(cfg->freqs, cfg->freqs + cfg->n_freqs);
     if (const char* e = std::getenv("SISIC_WINOGRAD")) u->use_winograd = std::atoi(e) != 0;
     if (const char* e = std::getenv("SISIC_FUSED_GN")) u->fuse_gn = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SISIC_GRAPH")) u->graph_mode = std::atoi(e) != 0 ? 1 : 0;
     u->cfg.freqs = nullptr;
     const int rc = describe(u);
     if (rc != SISIC_OK) { delete u; return rc; }
@@ -618,6 +626,9 @@ int sisic_unet_destroy(sisic_unet* u) {
     (void)sisic_unet_train_end(u);
     (void)hipDeviceSynchronize();
     pool_release_all(u);
+    for (float* p : {u->x_work, u->loop_tables, u->tproj_cur})
+        if (p) (void)hipFree(p);
+    if (u->loop_stream) (void)hipStreamDestroy(u->loop_stream);
     for (auto p : u->owned) (void)hipFree(p);
     for (float* p : {u->raw, u->t_vals, u->temb_act, u->tproj, u->gn_scale, u->gn_shift, u->eps_buf})
         if (p) (void)hipFree(p);
@@ -631,6 +642,12 @@ int sisic_unet_destroy(sisic_unet* u) {
 int sisic_unet_set_latency_mode(sisic_unet* u, int on) {
     SISIC_REQUIRE(u, "set_latency_mode: null handle");
     u->latency_mode = on != 0;
+    return SISIC_OK;
+}
+
+int sisic_unet_set_graph_mode(sisic_unet* u, int mode) {
+    SISIC_REQUIRE(u && mode >= -1 && mode <= 1, "set_graph_mode: mode must be -1 (follow latency mode), 0 or 1");
+    u->graph_mode = mode;
     return SISIC_OK;
 }
 
@@ -699,6 +716,108 @@ int sisic_unet_forward(sisic_unet* u, const float* sample, const int64_t* timest
     return run_forward(u, sample, u->tproj, uniform ? 0 : u->tproj_R, out, B, H, W, s);
 }
 
+// One denoising step with every per-step parameter selected on the device (elementwise.hip, LoopState): identical
+// launches for every step, so that a captured step can be replayed.
+static int loop_step(sisic_unet* u, int B, int H, int W, size_t n, float clip, hipStream_t s) {
+    void* state = u->loop_tables;
+    const float* coef_dev = u->loop_tables + 4;
+    const int* zrow_dev = reinterpret_cast<const int*>(u->loop_tables + 4 + 5 * 1000);
+    SISIC_TRY(launch_loop_select_row(u->ctx, u->tproj, u->tproj_R, state, u->tproj_cur, s));
+    SISIC_TRY(run_forward(u, u->x_work, u->tproj_cur, 0, u->eps_buf, B, H, W, s));
+    SISIC_TRY(launch_ddpm_step_indexed(u->ctx, u->eps_buf, u->x_work, (int64_t)n, state, coef_dev, zrow_dev, clip, s));
+    return launch_loop_advance(u->ctx, state, s);
+}
+
+// The loop as ONE captured step replayed T-1 times (hipGraph): at batch 1 a step is ~190 launches of 5-20 us kernels and
+// the host cannot issue them as fast as the GPU retires them (measured: 3.0 ms of kernels in a 4.5 ms step).
+static int sample_graph(sisic_unet* u, float* x, int B, int H, int W, int T, const float* coef, float clip, const float* noise,
+                        float* traj, const volatile int* cancel, int* steps_done, hipStream_t caller) {
+    const int C = u->cfg.in_channels;
+    const size_t n = (size_t)B * C * H * W;
+    SISIC_REQUIRE(T <= 1000, "sample: at most 1000 steps per call");
+    hipStream_t s = caller;
+    if (!s) {                              // the legacy default stream cannot be captured: a blocking stream of our own,
+        if (!u->loop_stream) SISIC_HIP(hipStreamCreate(&u->loop_stream));     // implicitly ordered with the default stream
+        s = u->loop_stream;
+    }
+    SISIC_TRY(grow(&u->x_work, &u->x_work_cap, n));
+    SISIC_TRY(grow(&u->tproj_cur, &u->tproj_cur_cap, (size_t)u->tproj_R));
+    SISIC_TRY(grow(&u->loop_tables, &u->loop_tables_cap, (size_t)4 + 5 * 1000 + 1000));
+    // tables of this call: {step = 0, noise base}, coefficients, noise row per step (-1: the step adds no noise)
+    std::vector<float> tab(4 + 5 * 1000 + 1000, 0.0f);
+    {
+        int step0 = 0;
+        std::memcpy(&tab[0], &step0, sizeof(int));
+        std::memcpy(&tab[2], &noise, sizeof(noise));
+        std::memcpy(&tab[4], coef, (size_t)T * 5 * sizeof(float));
+        int* zr = reinterpret_cast<int*>(&tab[4 + 5 * 1000]);
+        int zi = 0;
+        for (int i = 0; i < T; ++i) zr[i] = (noise && coef[(size_t)i * 5 + 4] != 0.0f) ? zi++ : -1;
+    }
+    SISIC_TRY(stage_upload(u, tab.data(), tab.size(), u->loop_tables, s));
+    SISIC_HIP(hipMemcpyAsync(u->x_work, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+
+    auto after_step = [&](int i) -> int {
+        if (traj) SISIC_HIP(hipMemcpyAsync(traj + (size_t)i * n, u->x_work, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (steps_done) *steps_done = i + 1;
+        return SISIC_OK;
+    };
+    int rc = SISIC_OK;
+    int i = 0;
+    auto cancelled = [&](int at) -> bool {
+        if (!cancel) return false;
+        if ((at & 7) == 0) (void)hipStreamSynchronize(s);
+        return *cancel != 0;
+    };
+    if (cancelled(0)) rc = SISIC_ECANCEL;
+    if (rc == SISIC_OK) {
+        // step 0 eagerly: sizes the pool and every scratch buffer, opts the kernels in to their LDS sizes
+        rc = loop_step(u, B, H, W, n, clip, s);
+        if (rc == SISIC_OK) rc = after_step(0);
+        i = 1;
+    }
+    if (rc == SISIC_OK && T > 1) {
+        const uint64_t gen = u->ctx->scratch_generation.load();
+        // every address baked into the captured launches: a longer run re-allocates the time-embedding table (found as a
+        // GPU memory fault when a T=50 run followed a T=8 run), a larger batch the latent / eps buffers
+        const void* ptrs[5] = {u->tproj, u->eps_buf, u->x_work, u->loop_tables, u->tproj_cur};
+        bool reuse = u->loop_valid && u->loop_key.B == B && u->loop_key.H == H && u->loop_key.W == W &&
+                     u->loop_key.clip == clip && u->loop_key.s == s && u->loop_key.latency == u->latency_mode &&
+                     u->loop_key.gen == gen;
+        for (int k = 0; k < 5; ++k) reuse = reuse && u->loop_key.ptrs[k] == ptrs[k];
+        if (!reuse) {
+            loop_graph_drop(u);
+            SISIC_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            const int crc = loop_step(u, B, H, W, n, clip, s);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(s, &g);
+            if (crc != SISIC_OK || e != hipSuccess || !g) {
+                if (g) (void)hipGraphDestroy(g);
+                if (crc == SISIC_OK) set_error("sample: stream capture failed: %s", hipGetErrorString(e));
+                return crc != SISIC_OK ? crc : SISIC_EHIP;
+            }
+            u->loop_graph = g;
+            SISIC_HIP(hipGraphInstantiate(&u->loop_exec, g, nullptr, nullptr, 0));
+            u->loop_key.B = B; u->loop_key.H = H; u->loop_key.W = W; u->loop_key.clip = clip; u->loop_key.s = s;
+            u->loop_key.latency = u->latency_mode; u->loop_key.gen = gen;
+            for (int k = 0; k < 5; ++k) u->loop_key.ptrs[k] = ptrs[k];
+            u->loop_valid = true;
+        }
+        for (; i < T; ++i) {
+            if (cancelled(i)) { rc = SISIC_ECANCEL; break; }
+            SISIC_HIP(hipGraphLaunch(u->loop_exec, s));
+            SISIC_TRY(after_step(i));
+        }
+    }
+    SISIC_HIP(hipMemcpyAsync(x, u->x_work, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (s != caller) SISIC_HIP(hipStreamSynchronize(s));      // hand the result back to the default stream's order
+    if (rc == SISIC_ECANCEL) {
+        SISIC_HIP(hipStreamSynchronize(s));
+        set_error("sample: cancelled after %d of %d steps", steps_done ? *steps_done : i, T);
+    }
+    return rc;
+}
+
 int sisic_sample(sisic_unet* u, float* x, int B, int H, int W, int T, const int64_t* timesteps, const float* coef,
                  float clip, const float* noise, float* traj, uint8_t* out_u8, const volatile int* cancel,
                  int* steps_done, void* stream) {
@@ -717,6 +836,15 @@ int sisic_sample(sisic_unet* u, float* x, int B, int H, int W, int T, const int6
     for (int i = 0; i < T; ++i) tv[i] = (float)timesteps[i];
     SISIC_TRY(stage_upload(u, tv.data(), (size_t)T, u->t_vals, s));
     SISIC_TRY(time_embed(u, T, s));
+
+    const bool use_graph = (u->graph_mode < 0 ? u->latency_mode : u->graph_mode != 0) && !u->ctx->profiling && T >= 4 && T <= 1000;
+    if (use_graph) {
+        if (!s) SISIC_HIP(hipStreamSynchronize(s));           // the embeddings above ran on the default stream
+        const int rc = sample_graph(u, x, B, H, W, T, coef, clip, noise, traj, cancel, steps_done, s);
+        if (rc != SISIC_OK) return rc;
+        if (out_u8) SISIC_TRY(launch_denorm_u8(u->ctx, x, out_u8, B, C, H, W, s));
+        return SISIC_OK;
+    }
 
     size_t zi = 0;
     for (int i = 0; i < T; ++i) {

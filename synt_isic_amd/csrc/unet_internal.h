@@ -183,6 +183,23 @@ struct sisic_unet {
     size_t eps_floats = 0;
     std::unique_ptr<sisic::TrainState> train;     // present after sisic_unet_train_begin
 
+    // graph-replayed sampling loop (sisic_sample): one captured step, replayed T-1 times
+    int graph_mode = -1;                 // -1: follow latency_mode (SISIC_GRAPH in the environment: 0 / 1 forces)
+    hipGraph_t loop_graph = nullptr;
+    hipGraphExec_t loop_exec = nullptr;
+    struct LoopKey {
+        int B = 0, H = 0, W = 0; float clip = 0; hipStream_t s = nullptr; bool latency = false; uint64_t gen = 0;
+        const void* ptrs[5] = {};        // tproj, eps_buf, x_work, loop_tables, tproj_cur at capture time: each can be re-allocated
+    } loop_key;
+    bool loop_valid = false;
+    hipStream_t loop_stream = nullptr;   // used when the caller's stream is the legacy default stream (not capturable)
+    float* x_work = nullptr;             // the loop's own latent buffer: every address inside the graph is library-owned
+    size_t x_work_cap = 0;
+    float* loop_tables = nullptr;        // [state 4 floats][coef 5*T][zrow T] device
+    size_t loop_tables_cap = 0;
+    float* tproj_cur = nullptr;
+    size_t tproj_cur_cap = 0;
+
     int add(const std::string& name, int64_t numel) {
         index[name] = (int)names.size();
         names.push_back(name);

@@ -121,6 +121,11 @@ class HipUNet2DModel:
             check(_lib.load().sisic_unet_set_latency_mode(self._handle, int(self._latency_mode)))
         return self
 
+    def set_graph_mode(self, mode: int = 1) -> "HipUNet2DModel":
+        """sisic_sample as a replayed hipGraph: 1 on, 0 off, -1 follow the latency mode (the default)."""
+        check(_lib.load().sisic_unet_set_graph_mode(self.handle, int(mode)))
+        return self
+
     def _ensure_training(self) -> None:
         """allocate the gradient and Adam arenas in the library (sisic_unet_train_begin), once"""
         if not self._train_begun:

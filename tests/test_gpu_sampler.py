@@ -246,3 +246,39 @@ def test_generate_postprocess_and_pth_round_trip(sampler, synthetic_sd, tmp_path
     assert np.array_equal(c, apply_color_statistics(a, stats["NV"])) and not np.array_equal(c, a)
     d, _ = s2.generate(5, "NV", 4, count=2, size=(32, 32), postprocess=False)
     assert np.array_equal(d, a)
+
+
+def test_graph_replayed_loop_is_bit_identical(synthetic_sd):
+    """sisic_sample with one captured step replayed T-1 times (hipGraph) against the launch-by-launch loop: same kernels,
+    same bits -- final latents, uint8 images and every trajectory frame -- for a run, a second run that reuses the cached
+    graph with other seeds, the segmented noise stream (several sisic_sample calls per run) and a cancelled run."""
+    from synt_isic_amd.sampler import Sampler
+    plain, graph = Sampler(DEV), Sampler(DEV)
+    plain.add_model("NV", synthetic_sd)
+    graph.add_model("NV", synthetic_sd).set_graph_mode(1)
+    plain.models["NV"].set_graph_mode(0)
+    for seeds, T in (([0, 1], 12), ([7, 8], 12), ([3], 9)):
+        a = plain.generate_seeds("NV", seeds, T, (32, 32), return_trajectory=True)
+        b = graph.generate_seeds("NV", seeds, T, (32, 32), return_trajectory=True)
+        assert b.steps_done == T
+        assert torch.equal(a.latents, b.latents) and torch.equal(a.images, b.images) and torch.equal(a.trajectory, b.trajectory)
+    graph.noise_segment_steps = plain.noise_segment_steps = 5            # three sisic_sample calls per run
+    a = plain.generate_seeds("NV", [11, 12, 13], 14, (32, 32))
+    b = graph.generate_seeds("NV", [11, 12, 13], 14, (32, 32))
+    assert torch.equal(a.latents, b.latents) and torch.equal(a.images, b.images)
+    # latency mode switches the graph on by itself; another resolution rebuilds it
+    lat = Sampler(DEV, latency_mode=True)
+    lat.add_model("NV", synthetic_sd)
+    r1 = lat.generate_seeds("NV", [5], 8, (64, 64))
+    r2 = lat.generate_seeds("NV", [5], 8, (64, 64))
+    r3 = lat.generate_seeds("NV", [5], 8, (32, 32))
+    assert torch.equal(r1.latents, r2.latents) and r3.latents.shape[-1] == 32 and torch.isfinite(r3.latents).all()
+    # a longer run after a shorter one re-allocates the time-embedding table the captured step reads: the graph is rebuilt
+    r4 = lat.generate_seeds("NV", [5], 40, (32, 32))
+    p4 = Sampler(DEV, latency_mode=True)
+    p4.add_model("NV", synthetic_sd).set_graph_mode(0)
+    assert torch.equal(r4.latents, p4.generate_seeds("NV", [5], 40, (32, 32)).latents)
+    lat.cancel.value = 1
+    rc = lat.generate_seeds("NV", [5], 8, (32, 32))
+    assert rc.cancelled and rc.steps_done == 0
+    lat.cancel.value = 0

@@ -54,6 +54,12 @@ LAYERS = [
     ("probe 16->64 @64 gn+res", 0, 16, 0, 64, 64, 3, 1, 0, 1, 1),
     ("probe 32->64 @64 gn+res", 0, 32, 0, 64, 64, 3, 1, 0, 1, 1),
     ("probe 128->64 @64 gn+res", 0, 128, 0, 64, 64, 3, 1, 0, 1, 1),
+    # 1x1: fixed cost vs contraction length (the UNet's 1x1 convolutions contract over 192..512 channels only)
+    ("probe1x1 128->256 @16", 0, 128, 0, 256, 16, 1, 1, 0, 0, 0),
+    ("probe1x1 256->256 @16", 0, 256, 0, 256, 16, 1, 1, 0, 0, 0),
+    ("probe1x1 512->256 @16", 0, 512, 0, 256, 16, 1, 1, 0, 0, 0),
+    ("probe1x1 1024->256 @16", 0, 1024, 0, 256, 16, 1, 1, 0, 0, 0),
+    ("probe1x1 2048->256 @16", 0, 2048, 0, 256, 16, 1, 1, 0, 0, 0),
 ]
 
 

@@ -37,6 +37,8 @@ def main():
     summary = {}
     conv_bytes = 0.0
     conv_calls = 0
+    main_bytes = 0.0
+    main_calls = 0
     for name, (n, v) in sorted(sq.items()):
         if not name.startswith("sisic::"):
             continue
@@ -56,7 +58,13 @@ def main():
         e["hbm_read_MB_per_launch_corrected"] = rd / 1e6
         e["hbm_write_MB_per_launch"] = wb / 1e6
         summary[name] = e
-        is_conv3 = ("conv_winograd_kernel" in name or re.search(r"conv_mfma_kernel<3,", name) or
+        # the dominant kernel family of bench.py's roofline (profile slot "conv3x3_winograd_main"): the stride-1, non-upsampled
+        # F(2x2,3x3) launches in their three geometries
+        is_main = (re.search(r"conv_winograd_wide_kernel<", name) or re.search(r"conv_winograd_kernel<1, 8, 8, \d, 16, false>", name))
+        if is_main:
+            main_bytes += (rd + wb) * n
+            main_calls += n
+        is_conv3 = ("conv_winograd_kernel" in name or "conv_winograd_wide_kernel" in name or re.search(r"conv_mfma_kernel<3,", name) or
                     "conv3x3_smallcout" in name or "splitk_reduce" in name)
         if is_conv3:
             conv_bytes += (rd + wb) * n
@@ -64,6 +72,9 @@ def main():
                 conv_calls += n
     summary["_conv3x3_all"] = {"hbm_MB_per_launch": conv_bytes / max(conv_calls, 1) / 1e6, "launches": conv_calls,
                                "note": "HBM bytes of all kernels launched by 3x3 convolutions / sisic_conv2d calls"}
+    summary["_winograd_main"] = {"hbm_MB_per_launch": main_bytes / max(main_calls, 1) / 1e6, "launches": main_calls,
+                                 "note": "HBM bytes per launch of the stride-1 F(2x2,3x3) kernels (conv_winograd_wide_kernel<128,16>, <64,8>, "
+                                         "conv_winograd_kernel<1,8,8,*,16,false>) = bench.py roofline.traffic"}
     with open(dst, "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print(json.dumps(summary["_conv3x3_all"]))
