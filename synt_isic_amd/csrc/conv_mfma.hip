@@ -443,12 +443,8 @@ static int launch_cfg(sisic_ctx* ctx, ConvParams& p, hipStream_t s) {
         const bool aligned = ((reinterpret_cast<uintptr_t>(p.in0) | reinterpret_cast<uintptr_t>(p.in1)) & 15) == 0;
         if (p.Wc % 4 == 0 && aligned) {
             auto kern4 = conv_mfma_kernel<KS, STRIDE, MT, NT, WM, WN, TW, CIC, OCC, KSP, true>;
-            static bool attr4_set = false;
-            if (!attr4_set) {
-                SISIC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern4), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)G::LDS_BYTES));
-                attr4_set = true;
-            }
+            static std::atomic<uint64_t> lds_opt_in4{0};     // one bit per device (common.h)
+            SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern4), (int)G::LDS_BYTES, lds_opt_in4));
             hipLaunchKernelGGL(kern4, dim3(p.nwg), dim3(G::NTHR), G::LDS_BYTES, s, p);
             SISIC_HIP(hipGetLastError());
             return SISIC_OK;
@@ -614,6 +610,8 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
             case 25: return launch_cfg<1, 1, 1, 1, 2, 4, 128, 32, 4>(ctx, p, s);
             case 26: return launch_cfg<1, 1, 1, 2, 2, 4, 256, 16, 4>(ctx, p, s);
             case 27: return launch_cfg<1, 1, 1, 1, 2, 4, 128, 16, 4>(ctx, p, s);
+            // (four-wave tiles at three / six workgroups per CU were measured too -- profiles/r02/conv1x1_tilings_and_contraction.txt,
+            //  cfg 28 / 29: within 2 % of 24 / slower -- and removed: occupancy is not what limits these launches)
         }
     } else if (a.stride == 1) {
         if (cfg == 0) cfg = p.Wout >= 24 ? 8 : (p.Wout >= 12 ? 9 : 16);   // measured (tools/conv_bench.py, B=64)

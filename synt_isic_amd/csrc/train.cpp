@@ -124,15 +124,16 @@ struct Bwd {
         }
         // ---- bias and time-embedding projection: sums of dy over the pixels of each (sample, channel) plane
         float* S = tr->small;                                  // [B, Cout]
+        SISIC_TRY(launch_plane_sums(u->ctx, dy, B * c.cout, Ho * Wo, S, s));
         if (op.qkv_of) {
             float* tmp = tr->small + (size_t)B * c.cout;       // [3C]
-            SISIC_TRY(launch_bias_grad(u->ctx, dy, B, c.cout, Ho * Wo, S, tmp, s));
+            SISIC_TRY(launch_col_sums(u->ctx, S, B, c.cout, c.cout, tmp, 0, s));
             const int C = op.qkv_of->c;
             const int idx[3] = {op.qkv_of->q_b, op.qkv_of->k_b, op.qkv_of->v_b};
             for (int i = 0; i < 3; ++i)
                 SISIC_HIP(hipMemcpyAsync(grad_of(u, idx[i]), tmp + (size_t)i * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, s));
         } else {
-            SISIC_TRY(launch_bias_grad(u->ctx, dy, B, c.cout, Ho * Wo, S, grad_of(u, c.b_idx), s));
+            SISIC_TRY(launch_col_sums(u->ctx, S, B, c.cout, c.cout, grad_of(u, c.b_idx), 0, s));
         }
         if (op.temb_off >= 0) SISIC_TRY(launch_copy_cols(u->ctx, S, B, c.cout, tr->dtproj + op.temb_off, u->tproj_R, s));
         // ---- weights

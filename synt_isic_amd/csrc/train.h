@@ -21,7 +21,6 @@ size_t conv_wgrad_scratch_floats(const WgradArgs& a);
 int launch_conv_wgrad(sisic_ctx*, const WgradArgs& a, float* part, size_t part_floats, hipStream_t s);
 int launch_transpose_flip(sisic_ctx*, const float* w, int Cout, int Cin, int KK, float* wt, hipStream_t s);
 int launch_plane_sums(sisic_ctx*, const float* x, int planes, int HW, float* out, hipStream_t s);
-int launch_bias_grad(sisic_ctx*, const float* dy, int B, int C, int HW, float* S, float* db, hipStream_t s);
 int launch_col_sums(sisic_ctx*, const float* m, int rows, int cols, int ld, float* out, int accumulate, hipStream_t s);
 int launch_copy_cols(sisic_ctx*, const float* src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);
 // sums: scratch [2][B][c0+c1]

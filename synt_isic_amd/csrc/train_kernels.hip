@@ -327,30 +327,6 @@ int launch_plane_sums(sisic_ctx*, const float* x, int planes, int HW, float* out
     return SISIC_OK;
 }
 
-// Bias gradient and per-sample plane sums in one pass over dy: S[b,c] = sum_hw dy[b,c,:], db[c] = sum_b S[b,c].
-// One workgroup per channel, fixed order.
-__global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ dy, int B, int C, int HW, float* __restrict__ S,
-                                                        float* __restrict__ db) {
-    __shared__ float red[4];
-    const int c = blockIdx.x;
-    float total = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        const float* src = dy + ((size_t)b * C + c) * HW;
-        float s = 0.0f;
-        for (int i = threadIdx.x; i < HW; i += 256) s += src[i];
-        s = block_sum_256(s, red);
-        if (threadIdx.x == 0) S[(size_t)b * C + c] = s;
-        total += s;
-    }
-    if (threadIdx.x == 0 && db) db[c] = total;
-}
-
-int launch_bias_grad(sisic_ctx*, const float* dy, int B, int C, int HW, float* S, float* db, hipStream_t s) {
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, s, dy, B, C, HW, S, db);
-    SISIC_HIP(hipGetLastError());
-    return SISIC_OK;
-}
-
 // out[c] (+)= sum_r m[r * ld + c]
 __global__ void col_sum_kernel(const float* __restrict__ m, int rows, int cols, int ld, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
