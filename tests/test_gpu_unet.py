@@ -175,5 +175,11 @@ def test_latency_mode(synthetic_sd, golden_dir):
     d.load_state_dict(synthetic_sd)
     d = d.to(DEV).eval()
     assert (d(x128, int(g["t"])).sample - y).abs().max().item() <= 2e-5     # the two modes differ by rounding only
+    # a non-square resolution with ragged tiles at every level (40x56 -> 20x28 -> 10x14 -> 5x7), against the oracle
+    from oracle import unet as ounet
+    xr = torch.randn(2, 3, 40, 56, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = ounet.unet_forward(synthetic_sd, xr, torch.tensor([3, 977]))
+    assert (m(xr.to(DEV), torch.tensor([3, 977])).sample.cpu() - ref).abs().max().item() <= FWD_TOL
     m.set_latency_mode(False)
     assert torch.equal(m(x128, int(g["t"])).sample, d(x128, int(g["t"])).sample)
