@@ -491,13 +491,9 @@ static int winograd_cfg(const sisic_conv_args& a) {
     if (Hout >= 12 && Wout >= 12) {
         // second geometry (conv_winograd_wide.inc) unless SISIC_WINO_WIDE=0; nearest-2x inputs keep the nine-position form
         static const bool wide_on = [] { const char* e = std::getenv("SISIC_WINO_WIDE"); return !e || std::atoi(e) != 0; }();
-        // measured per layer (tools/conv_bench.py, profiles/r02/conv_bench_geometries.txt): 128-channel tiles win 2-4 % on
-        // every Cout >= 128 layer; the 64-channel two-workgroups-per-CU form saves ~10 us of un-overlapped prologue /
-        // output-transform time per launch but runs 8 % longer per chunk, so it pays up to 8 chunks (Cin <= 64)
-        if (wide_on && !a.upsample) {
-            if (a.Cout > 64) return 68;
-            if (a.c0 + a.c1 <= 64) return 69;
-        }
+        // measured per layer (tools/conv_bench.py, profiles/r02/conv_bench_geometries.txt): the 128-channel form wins 8-12 % on
+        // every Cout >= 128 layer, the 64-channel two-workgroups-per-CU form 1-10 % on every Cout <= 64 layer
+        if (wide_on && !a.upsample) return a.Cout > 64 ? 68 : 69;
         return 66;
     }
     // the 8x8 level (and the classifier's 7x7): four images per workgroup and the input channels split four ways

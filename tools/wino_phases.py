@@ -22,7 +22,7 @@ PHASES = ["index plans", "first chunk loaded+staged", "transform(0), stage(1)", 
           "output transform", "stores retired"]
 
 
-def run(cin, cout, hw, B=64, gn=True, res=True, clock_ghz=2.4):
+def run(cin, cout, hw, B=64, gn=True, res=True, clock_ghz=2.4, cfg=66):
     dev = torch.device("cuda")
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
@@ -40,7 +40,13 @@ def run(cin, cout, hw, B=64, gn=True, res=True, clock_ghz=2.4):
         a.gn_scale = sc.data_ptr(); a.gn_shift = sh.data_ptr(); a.gn_silu = 1
     if res:
         a.residual = r.data_ptr()
-    nwg = B * ((hw + 15) // 16) ** 2 * ((cout + 63) // 64)
+    a.tile_cfg = cfg
+    if cfg == 68:
+        nwg = B * ((hw + 7) // 8) * ((hw + 15) // 16) * ((cout + 127) // 128)
+    elif cfg == 69:
+        nwg = B * ((hw + 7) // 8) * ((hw + 15) // 16) * ((cout + 63) // 64)
+    else:
+        nwg = B * ((hw + 15) // 16) ** 2 * ((cout + 63) // 64)
     stamps = torch.zeros(nwg * 8 + 64, dtype=torch.int64, device=dev)
     a.stats_out = stamps.data_ptr()
     for _ in range(3):
@@ -49,14 +55,18 @@ def run(cin, cout, hw, B=64, gn=True, res=True, clock_ghz=2.4):
     t = stamps[: nwg * 8].view(nwg, 8).cpu().double()
     d = (t[:, 1:] - t[:, :-1]) / (clock_ghz * 1e3)
     life = (t[:, 7] - t[:, 0]) / (clock_ghz * 1e3)
-    print(f"--- {cin}->{cout} @{hw}x{hw} B={B} ({nwg} workgroups, {cin // 8} chunks), median us per workgroup "
+    print(f"--- cfg {cfg}: {cin}->{cout} @{hw}x{hw} B={B} ({nwg} workgroups, {cin // 8} chunks), median us per workgroup "
           f"(assuming {clock_ghz} GHz); workgroup life {life.median():.2f}")
     for name, col in zip(PHASES, d.t()):
         print(f"   {name:28s} {col.median():7.2f}   (p10 {col.quantile(0.1):6.2f}, p90 {col.quantile(0.9):6.2f})")
 
 
 if __name__ == "__main__":
-    run(8, 64, 64)
-    run(64, 64, 64)
-    run(128, 128, 32)
-    run(256, 256, 16)
+    for cfg in (66, 69):
+        run(8, 64, 64, cfg=cfg)
+        run(64, 64, 64, cfg=cfg)
+        run(128, 64, 64, cfg=cfg)
+    for cfg in (66, 68):
+        run(128, 128, 32, cfg=cfg)
+        run(256, 256, 16, cfg=cfg)
+        run(512, 256, 16, cfg=cfg)
