@@ -257,7 +257,7 @@ def main():
         roofline = {
             "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (GroupNorm+SiLU prologue, "
                       "bias/temb/residual + GroupNorm partials epilogue): conv_winograd_wide_kernel<128,16> (Cout > 64), "
-                      "conv_winograd_wide_kernel<64,8> (Cin, Cout <= 64), conv_winograd_kernel<1,8,8,PRO,16,false> (Cout <= 64 < Cin)",
+                      "conv_winograd_wide_kernel<64,8> (Cout <= 64, two workgroups per CU)",
             "bound": "mfma",
             "achieved": d_exec,
             "peak": PEAK_FP32_MFMA_TFLOPS,
