@@ -473,7 +473,7 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 //            6: 2,1,1,4,TW64   7: 2,1,1,4,TW32 (PIX128)   8: 1,2,2,4,TW32   9: 1,2,2,4,TW16 (8 waves, PIX256)
 //           14: 1,1,2,4,TW16  15: 1,1,2,4,TW8 (8 waves, PIX128)   50: vector-ALU kernel for Cout <= 4
 //           16 / 17: cfg 4's 64x64 tile with two K-split wave groups (8 waves), 16- / 8-channel chunks
-//   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8
+//   3x3 s2: 11: 2,1,1,4,TW32  12: 2,1,1,4,TW16  13: 1,1,2,2,TW8   18 / 19: cfg 13's tile with two K-split wave groups, 16- / 8-channel chunks
 //   1x1   : 21: 2,2,1,4,TW256 22: 1,1,2,2,TW64  23: 2,1,1,4,TW128
 //   1x1 s2: 31: 2,1,1,4,TW32  32: 2,1,1,4,TW16  33: 1,1,2,2,TW8      7x7 s2: 41: 2,1,1,4,TW32 (CIC 4)
 static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s, int* slots_query);
@@ -571,7 +571,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
                       use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops,
                       (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || winograd_cfg(a) == 68 || winograd_cfg(a) == 69 || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
 
-    if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50)) {
+    if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50 || cfg == 51)) {
         if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)
         return launch_conv_smallcout(ctx, a, s);      // conv_out: vector-ALU kernel, conv_small.hip
     }
@@ -628,11 +628,13 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
             case 15: return launch_cfg<3, 1, 1, 1, 2, 4, 8, 8, 4>(ctx, p, s);
         }
     } else {
-        if (cfg == 0) cfg = p.Wout >= 24 ? 11 : (p.Wout >= 12 ? 12 : 13);
+        if (cfg == 0) cfg = p.Wout >= 24 ? 11 : (p.Wout >= 12 ? 12 : 18);   // measured (tools/conv_bench.py, B=64; 16->8: 66 -> 57 us)
         switch (cfg) {
             case 11: return launch_cfg<3, 2, 2, 1, 1, 4, 32, 8>(ctx, p, s);
             case 12: return launch_cfg<3, 2, 2, 1, 1, 4, 16, 8>(ctx, p, s);
             case 13: return launch_cfg<3, 2, 1, 1, 2, 2, 8, 8>(ctx, p, s);
+            case 18: return launch_cfg<3, 2, 1, 1, 2, 2, 8, 16, 2, 2>(ctx, p, s);   // latency mode: 8x8 pixels, 8 waves = 2 K groups x (2x2)
+            case 19: return launch_cfg<3, 2, 1, 1, 2, 2, 8, 8, 2, 2>(ctx, p, s);
         }
     }
     set_error("conv2d: tile_cfg %d invalid for ksize %d stride %d", cfg, a.ksize, a.stride);

@@ -15,14 +15,22 @@
 
 namespace sisic {
 
-constexpr int CS_TW = 32, CS_TH = 32, CS_PX = 4, CS_CIC = 2, CS_THR = (CS_TW / CS_PX) * CS_TH;   // 256 threads
-constexpr int CS_IW = CS_TW + 2, CS_IH = CS_TH + 2;
+// Tile = 32 x CS_TH output pixels.  CS_TH = 32 (256 threads) when the launch has workgroups to spare; 8 (one wave) when it
+// does not (a single 128x128 image is 16 tiles of 32x32).  A pixel's sum runs over the channels in the same order either
+// way, so the choice never changes a bit of the result.
+constexpr int CS_TW = 32, CS_PX = 4, CS_CIC = 2;
+constexpr int CS_IW = CS_TW + 2;
 constexpr int CS_IWP = 36;                                       // LDS row stride: float4-aligned rows
-constexpr int CS_TPC = CS_THR / CS_CIC;                          // 128 threads stage one channel
-constexpr int CS_EPT = (CS_IH * CS_IWP + CS_TPC - 1) / CS_TPC;   // 10
-constexpr int CS_CHS = CS_EPT * CS_TPC;                          // 1280 floats per channel (padded)
-static_assert(CS_IWP >= CS_IW + 2 && CS_IWP % 4 == 0 && CS_CHS % 4 == 0, "aligned rows");
-static_assert(CS_CIC * 9 <= CS_THR, "one thread per filter row");
+template <int CS_TH>
+struct CSGeom {
+    static constexpr int THR = (CS_TW / CS_PX) * CS_TH;          // 256 / 64 threads
+    static constexpr int IH = CS_TH + 2;
+    static constexpr int TPC = THR / CS_CIC;                     // threads staging one channel
+    static constexpr int EPT = (IH * CS_IWP + TPC - 1) / TPC;    // 10 / 12
+    static constexpr int CHS = EPT * TPC;                        // floats per channel (padded)
+    static_assert(CS_IWP >= CS_IW + 2 && CS_IWP % 4 == 0 && CHS % 4 == 0, "aligned rows");
+    static_assert(CS_CIC * 9 <= THR, "one thread per filter row");
+};
 
 struct ConvSmallParams {
     const float* in0;
@@ -43,7 +51,10 @@ struct ConvSmallParams {
     int tiles_x, tiles_y, nchunks;
 };
 
-__global__ void __launch_bounds__(CS_THR, 3) conv3x3_smallcout_kernel(const ConvSmallParams p) {
+template <int CS_TH>
+__global__ void __launch_bounds__(CSGeom<CS_TH>::THR, 3) conv3x3_smallcout_kernel(const ConvSmallParams p) {
+    constexpr int CS_THR = CSGeom<CS_TH>::THR, CS_IH = CSGeom<CS_TH>::IH, CS_TPC = CSGeom<CS_TH>::TPC, CS_EPT = CSGeom<CS_TH>::EPT,
+                  CS_CHS = CSGeom<CS_TH>::CHS;
     __shared__ __attribute__((aligned(16))) float in_lds[2][CS_CIC * CS_CHS];
     __shared__ __attribute__((aligned(16))) float w_lds[2][CS_CIC * 9 * 4];
 
@@ -179,11 +190,15 @@ int launch_conv_smallcout(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t 
     p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift; p.gn_silu = a.gn_silu;
     p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu;
     p.out = a.out;
-    p.tiles_x = cdiv(a.Win, CS_TW); p.tiles_y = cdiv(a.Hin, CS_TH);
+    p.tiles_x = cdiv(a.Win, CS_TW);
     p.nchunks = cdiv(a.c0 + a.c1, CS_CIC);
+    // tile_cfg 50 / 51 force the 32- / 8-row tile (tools/conv_bench.py); otherwise 32 rows from one workgroup per CU up
+    const bool spare = a.tile_cfg == 50 || (a.tile_cfg != 51 && (int64_t)a.B * p.tiles_x * cdiv(a.Hin, 32) >= 256);
+    p.tiles_y = cdiv(a.Hin, spare ? 32 : 8);
     const int64_t nwg = (int64_t)a.B * p.tiles_x * p.tiles_y;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d(small): grid too large");
-    hipLaunchKernelGGL(conv3x3_smallcout_kernel, dim3((unsigned)nwg), dim3(CS_THR), 0, s, p);
+    if (spare) hipLaunchKernelGGL(conv3x3_smallcout_kernel<32>, dim3((unsigned)nwg), dim3(CSGeom<32>::THR), 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_smallcout_kernel<8>, dim3((unsigned)nwg), dim3(CSGeom<8>::THR), 0, s, p);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

@@ -370,6 +370,7 @@ struct Fwd {
             // inside this mode an image's bits are again independent of the batch.
             if (c.k == 3 && stride == 1 && !ups && a.w_winograd && c.cout > 4 && H >= 12 && W >= 12) a.tile_cfg = c.cout > 64 ? 78 : 79;
             else if (c.k == 1 && stride == 1) a.tile_cfg = 22;
+            else if (c.k == 3 && stride == 2) a.tile_cfg = 18;      // 8x8-pixel tiles, two K groups of waves: 189 -> 105 us for the three downsamplers of one 128x128 image
         }
         if (normed_later && u->fuse_gn) {          // a GroupNorm reads this output: have the epilogue leave partials
             const int slots = conv_stats_slots(a);

@@ -107,11 +107,15 @@ def test_conv3x3_small_cout_kernel(H, W):
         b = _rand(cout, seed=90 + cout)
         res = _rand(B, cout, H, W, seed=95 + cout)
         cb = _rand(B, cout, seed=99 + cout)
-        for cfg in (0, 50):
+        outs = {}
+        for cfg in (0, 50, 51):
             kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True)
-            _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"small-cout {cout} cfg{cfg} {H}x{W}")
+            outs[cfg] = _run_conv(x, w, cfg, **kw)
+            _close(outs[cfg], _conv_ref(x, w, **kw), what=f"small-cout {cout} cfg{cfg} {H}x{W}")
             kw = dict(bias=b, x2=x2, gn=gn, gn_silu=False, chan_bias=cb, residual=res, relu=True)
             _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"small-cout fused {cout} cfg{cfg}")
+        # the 32-row and the 8-row tile (picked from the number of workgroups) sum a pixel's channels in the same order
+        assert torch.equal(outs[50], outs[51]) and torch.equal(outs[0], outs[50])
     w = _rand(3, 64, 3, 3, seed=101, scale=0.05)
     x = _rand(1, 64, H, W, seed=102)
     _close(_run_conv(x, w, 0), _conv_ref(x, w), what="small-cout plain 64->3")
@@ -293,7 +297,7 @@ def test_conv3x3_upsample(cfg, H, W):
 
 
 @pytest.mark.parametrize("cfg,H,W", [(0, 64, 64), (0, 32, 32), (0, 16, 16), (11, 64, 64), (12, 32, 32), (13, 16, 16),
-                                     (11, 20, 36), (13, 6, 10)])
+                                     (11, 20, 36), (13, 6, 10), (18, 16, 16), (18, 20, 36), (19, 32, 32), (19, 6, 10)])
 def test_conv3x3_stride2(cfg, H, W):
     x = _rand(2, 16, H, W, seed=19)
     w = _rand(64, 16, 3, 3, seed=20, scale=0.1)
