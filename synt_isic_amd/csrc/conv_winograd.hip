@@ -928,6 +928,7 @@ static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
 //          78 / 79: 68 / 69 in latency mode: input channels K-split so that one image fills the chip (wino_latency_ksplit)
 //          90: tiling 67 with the input channels split over four workgroups per tile + splitk_reduce_kernel -- for the
 //              8x8 level, where 64 tiles x 64 channels per workgroup leave 3/4 of the CUs without work
+//          91: the same split on the second geometry: 128 channels x (two images x 16 tiles) per workgroup; bit-identical to 90
 int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s) {
     WinoParams p{};
     p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1;
@@ -977,7 +978,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         SISIC_HIP(hipGetLastError());
         return SISIC_OK;
     }
-    if (cfg == 90) {
+    if (cfg == 90 || cfg == 91) {
         constexpr int K = 4;
         const size_t HW = (size_t)p.Hc * p.Wc, planes = (size_t)a.B * a.Cout;
         SISIC_REQUIRE(HW <= 256 && (cdiv(a.c0 + a.c1, W_CIC) % K) == 0,
@@ -999,7 +1000,14 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         }
         p.ksplit = K;
         p.part = scratch;
-        SISIC_TRY((launch_wino_pro<4, 4, 4, 16>(ctx, p, s)));
+        if (cfg == 91) {          // second geometry, two images per workgroup (conv_winograd_wide.inc, PAIR)
+            SISIC_REQUIRE(!p.ups && p.Hc <= 8 && p.Wc <= 8, "conv2d(winograd wide, image pairs): plain stride-1 convolutions of at most 8x8 pixels");
+            p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1);
+            p.cout_pad = round_up(a.Cout, 128);
+            SISIC_TRY((launch_wide_pro<128, 16, true>(ctx, p, s)));
+        } else {
+            SISIC_TRY((launch_wino_pro<4, 4, 4, 16>(ctx, p, s)));
+        }
         hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, scratch,
                            (int)planes, (int)HW, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu,
                            a.out, a.stats_out);

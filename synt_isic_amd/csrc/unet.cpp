@@ -368,7 +368,9 @@ struct Fwd {
             // convolutions split their input channels over workgroups (tile_cfg 78 / 79) and the 1x1 convolutions take the
             // 64-pixel tiles, so that one image offers a few hundred workgroups per layer.  Chosen from the layer shape only:
             // inside this mode an image's bits are again independent of the batch.
-            if (c.k == 3 && stride == 1 && !ups && a.w_winograd && c.cout > 4 && H >= 12 && W >= 12) a.tile_cfg = c.cout > 64 ? 78 : 79;
+            // (the 64-channel, two-workgroups-per-CU form for every Cout: at one image it is level with or ahead of the
+            //  128-channel form on every layer, profiles/r02/ksplit_in_place_ab.txt rows 76 (128-channel) / 77 (64-channel))
+            if (c.k == 3 && stride == 1 && !ups && a.w_winograd && c.cout > 4 && H >= 12 && W >= 12) a.tile_cfg = 79;
             else if (c.k == 1 && stride == 1) a.tile_cfg = 22;
             else if (c.k == 3 && stride == 2) a.tile_cfg = 18;      // 8x8-pixel tiles, two K groups of waves: 189 -> 105 us for the three downsamplers of one 128x128 image
         }

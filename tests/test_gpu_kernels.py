@@ -251,6 +251,42 @@ def test_conv3x3_winograd_ksplit(B, H, W, c0, c1, cout):
         _run_wino(x[:, :24].contiguous(), w[:, :24].contiguous(), 90)        # 3 chunks do not split four ways
 
 
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(8, 8, 8, 64, 0, 64), (5, 8, 8, 40, 24, 70), (3, 6, 7, 96, 0, 128),
+                                              (32, 8, 8, 128, 0, 128), (1, 7, 7, 64, 0, 200), (2, 4, 4, 32, 0, 256)])
+def test_conv3x3_winograd_ksplit_image_pairs(B, H, W, c0, c1, cout):
+    """tile_cfg 91: the K-split of tile_cfg 90 on the second geometry -- 128 channels x (two images of <= 4x4 tiles) per
+    workgroup, odd batches leave the second image of the last pair empty.  Same filters, same channel order, same
+    reduction: every bit equals tile_cfg 90's."""
+    x = _rand(B, c0, H, W, seed=290)
+    x2 = _rand(B, c1, H, W, seed=291) if c1 else None
+    w = _rand(cout, c0 + c1, 3, 3, seed=292, scale=0.05)
+    b = _rand(cout, seed=293)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=294), 0.3 * _rand(B, c0 + c1, seed=295))
+    cb = _rand(B, cout, seed=296)
+    res = _rand(B, cout, H, W, seed=297)
+    for kw in (dict(bias=b, x2=x2, gn=gn, gn_silu=True, chan_bias=cb, residual=res), dict(bias=b, x2=x2, relu=True),
+               dict(bias=b, x2=x2, gn=gn, gn_silu=False)):
+        y = _run_wino(x, w, 91, **kw)
+        _close(y, _conv_ref(x, w, **kw), tol=KTOL, what="winograd K-split, image pairs")
+        assert torch.equal(y, _run_wino(x, w, 90, **kw))
+    # GroupNorm partials from the reduction: one slot per (image, channel) plane
+    from synt_isic_amd import ops
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 3, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=91,
+                       w_winograd=ops.pack_winograd_weight(d(w)), with_stats=True)
+    assert st is not None and tuple(st.shape) == (B, cout, 1, 4)
+    G = 2 if cout % 32 else 32
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=288), 0.1 * _rand(cout, seed=289)
+    sc, sh = ops.groupnorm_finalize(st, H * W, d(gamma), d(beta), G, 1e-5)
+    yc = y.cpu().double()
+    ref = F.group_norm(yc, G, gamma.double(), beta.double(), 1e-5)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=KTOL, what="groupnorm from the K-split reduction, image pairs")
+    from synt_isic_amd._lib import SisicError
+    with pytest.raises(SisicError, match="8x8"):
+        _run_wino(_rand(2, 32, 8, 10, seed=298), _rand(64, 32, 3, 3, seed=299), 91)
+
+
 def test_conv3x3_winograd_reference_layers_and_identity():
     # identity filter: the transform pair must reproduce the input up to fp32 rounding of the 1/2, 1/4 weights
     C = 64
