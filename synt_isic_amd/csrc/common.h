@@ -147,6 +147,8 @@ int launch_gn_finalize(sisic_ctx*, const float* st0, int c0, int slots0, const f
 int launch_conv_winograd(sisic_ctx*, const sisic_conv_args& a, const float* u_packed, int cfg, hipStream_t s);
 int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s);
 int64_t winograd_packed_numel(int Cout, int Cin);
+// floats of the first Winograd layout [Cin_pad][16][cout_pad]; the wide layout follows it in the same buffer
+inline int64_t winograd_first_floats(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * conv_cout_pad(Cout); }
 int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float* packed, hipStream_t s);
 int launch_gn_stats(sisic_ctx*, const float* in0, int c0, const float* in1, int c1, int B, int HW, int groups,
                     float eps, const float* gamma, const float* beta, float* scale, float* shift, hipStream_t s,

@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "pack_device.h"
 
 namespace sisic {
 
@@ -414,13 +415,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
                                  float* __restrict__ out) {
     const size_t total = (size_t)cin_pad * KK * cout_pad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % cout_pad);
-        const size_t r = i / cout_pad;
-        const int tap = (int)(r % KK);
-        const int ci = (int)(r / KK);
-        float v = 0.0f;
-        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KK + tap];
-        out[i] = v;
+        conv_pack_elem(i, w, Cout, Cin, KK, cin_pad, cout_pad, out);
     }
 }
 

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "pack_device.h"
 
 // Timing-only ablation builds for tools/conv_bench.py (results are wrong): bit 0 skips the MFMAs, bit 1 the
 // output transform, bit 2 the halo staging + input transform.  Never defined in the shipped library.
@@ -732,35 +733,13 @@ __global__ void winograd_pack_kernel(const float* __restrict__ w, int Cout, int 
                                      float* __restrict__ out) {
     const size_t total = (size_t)cin_pad * cout_pad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % cout_pad), ci = (int)(i / cout_pad);
-        double u[4][4];
-        if (co < Cout && ci < Cin) {
-            const float* g = w + ((size_t)co * Cin + ci) * 9;
-            double t[4][3];
-            for (int j = 0; j < 3; ++j) {
-                const double g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
-                t[0][j] = g0;
-                t[1][j] = 0.5 * (g0 + g1 + g2);
-                t[2][j] = 0.5 * (g0 - g1 + g2);
-                t[3][j] = g2;
-            }
-            for (int r = 0; r < 4; ++r) {
-                u[r][0] = t[r][0];
-                u[r][1] = 0.5 * (t[r][0] + t[r][1] + t[r][2]);
-                u[r][2] = 0.5 * (t[r][0] - t[r][1] + t[r][2]);
-                u[r][3] = t[r][2];
-            }
-        } else {
-            for (int r = 0; r < 4; ++r)
-                for (int c = 0; c < 4; ++c) u[r][c] = 0.0;
-        }
-        for (int xi = 0; xi < 16; ++xi) out[((size_t)ci * 16 + xi) * cout_pad + co] = (float)u[xi >> 2][xi & 3];
+        winograd_pack_elem(i, w, Cout, Cin, cin_pad, cout_pad, out);
     }
 }
 
 // two packings back to back: [Cin_pad][16][cout_pad] (first form) and [chunk][xi][32-ch block][lane][4] (wide form, its
 // channel blocks padded to whole 128-channel tiles)
-static int64_t winograd_first_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * conv_cout_pad(Cout); }
+static int64_t winograd_first_numel(int Cout, int Cin) { return winograd_first_floats(Cout, Cin); }
 static int64_t winograd_wide_numel(int Cout, int Cin) { return (int64_t)round_up(Cin, 16) * 16 * round_up(Cout, 128); }
 __global__ void winograd_pack_wide_kernel(const float* __restrict__ u_first, int cin_pad, int cout_pad, int cout_pad128,
                                           float* __restrict__ out);

@@ -5,6 +5,7 @@
 //   * linear_t_kernel   : every ResnetBlock2D.time_emb_proj in one launch
 //   * transpose2d_kernel: weight re-layout at load time
 #include "common.h"
+#include "pack_device.h"
 
 namespace sisic {
 
@@ -274,8 +275,7 @@ __global__ void transpose2d_kernel(const float* __restrict__ in, int rows, int c
                                    int out_ld, int out_col0) {
     const int64_t total = (int64_t)rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / cols), c = (int)(i % cols);
-        out[(size_t)c * out_ld + out_col0 + r] = in[i];
+        transpose2d_elem((size_t)i, in, cols, out, out_ld, out_col0);
     }
 }
 

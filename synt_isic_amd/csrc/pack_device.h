@@ -1,0 +1,78 @@
+// pack_device.h -- one destination element of each weight re-layout, shared by the stand-alone pack kernels (one launch per
+// tensor: load time) and pack_batch_kernel (repack.hip: every derived form of every weight in three launches after an
+// optimizer step).  One definition, so the two routes cannot drift apart.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sisic {
+
+// OIHW -> [Cin_pad][KK][cout_pad], zero padded (conv_mfma.hip)
+__device__ __forceinline__ void conv_pack_elem(size_t i, const float* __restrict__ w, int Cout, int Cin, int KK, int cin_pad,
+                                               int cout_pad, float* __restrict__ out) {
+    const int co = (int)(i % cout_pad);
+    const size_t r = i / cout_pad;
+    const int tap = (int)(r % KK);
+    const int ci = (int)(r / KK);
+    float v = 0.0f;
+    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * KK + tap];
+    out[i] = v;
+}
+
+// U = G g G^T of one (co, ci) pair, float64 arithmetic, written as [Cin_pad][16][cout_pad] (zero padded); i over cin_pad * cout_pad
+__device__ __forceinline__ void winograd_pack_elem(size_t i, const float* __restrict__ w, int Cout, int Cin, int cin_pad,
+                                                   int cout_pad, float* __restrict__ out) {
+    const int co = (int)(i % cout_pad), ci = (int)(i / cout_pad);
+    double u[4][4];
+    if (co < Cout && ci < Cin) {
+        const float* g = w + ((size_t)co * Cin + ci) * 9;
+        double t[4][3];
+        for (int j = 0; j < 3; ++j) {
+            const double g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+            t[0][j] = g0;
+            t[1][j] = 0.5 * (g0 + g1 + g2);
+            t[2][j] = 0.5 * (g0 - g1 + g2);
+            t[3][j] = g2;
+        }
+        for (int r = 0; r < 4; ++r) {
+            u[r][0] = t[r][0];
+            u[r][1] = 0.5 * (t[r][0] + t[r][1] + t[r][2]);
+            u[r][2] = 0.5 * (t[r][0] - t[r][1] + t[r][2]);
+            u[r][3] = t[r][2];
+        }
+    } else {
+        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) u[r][c] = 0.0;
+    }
+    for (int xi = 0; xi < 16; ++xi) out[((size_t)ci * 16 + xi) * cout_pad + co] = (float)u[xi >> 2][xi & 3];
+}
+
+// second packing of U for the wide form: [chunk][xi][32-channel block][lane = (ci & 1) * 32 + co % 32][(ci % 8) / 2];
+// i over cin_pad * 16 * cout_pad128, read from the first layout [ci][xi][co]
+__device__ __forceinline__ void winograd_pack_wide_elem(size_t i, const float* __restrict__ u_first, int cout_pad, int cout_pad128,
+                                                        float* __restrict__ out) {
+    const int n_co32 = cout_pad128 >> 5;
+    const int co = (int)(i % cout_pad128);
+    const size_t r = i / cout_pad128;
+    const int xi = (int)(r % 16), ci = (int)(r / 16);
+    const int chunk = ci >> 3, cp = (ci & 7) >> 1, hf = ci & 1;
+    const size_t o = ((((size_t)chunk * 16 + xi) * n_co32 + (co >> 5)) * 64 + hf * 32 + (co & 31)) * 4 + cp;
+    out[o] = co < cout_pad ? u_first[((size_t)ci * 16 + xi) * cout_pad + co] : 0.0f;
+}
+
+// W'[ci][co][KK-1-t] = W[co][ci][t]: the filter of the backward-data convolution; i over Cout * Cin * KK
+__device__ __forceinline__ void transpose_flip_elem(size_t i, const float* __restrict__ w, int Cout, int Cin, int KK,
+                                                    float* __restrict__ wt) {
+    const int t = (int)(i % KK);
+    const size_t cc = i / KK;
+    const int ci = (int)(cc % Cin), co = (int)(cc / Cin);
+    wt[((size_t)ci * Cout + co) * KK + (KK - 1 - t)] = w[i];
+}
+
+// out[c][out_col0 + r] = in[r][c]; i over rows * cols
+__device__ __forceinline__ void transpose2d_elem(size_t i, const float* __restrict__ in, int cols, float* __restrict__ out, int out_ld,
+                                                 int out_col0) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    out[(size_t)c * out_ld + out_col0 + r] = in[i];
+}
+
+}  // namespace sisic

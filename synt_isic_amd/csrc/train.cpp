@@ -47,6 +47,68 @@ int prepare_backward_conv(sisic_unet* u, ConvW& c, hipStream_t s) {
     return SISIC_OK;
 }
 
+// The job tables of repack.hip: everything prepare_all (unet.cpp) and prepare_backward_weights (below) derive from the raw
+// arena, in dependency order.  Built after those two have run once (they allocate); the destinations do not move afterwards.
+int build_repack_plan(sisic_unet* u) {
+    TrainState* tr = u->train.get();
+    std::vector<PackJob> ph[3];
+    const int nin = 2 * u->cfg.n_freqs;
+    ph[0].push_back(pack_job_transpose2d(u->rawp(u->temb_w1), u->hidden, nin, u->w1t, u->hidden, 0));
+    ph[0].push_back(pack_job_transpose2d(u->rawp(u->temb_w2), u->hidden, u->hidden, u->w2t, u->hidden, 0));
+    for (ConvW* c : unet_convs(u)) {
+        if (c->k == 0) continue;
+        const float* w = u->rawp(c->w_idx);
+        SISIC_REQUIRE(c->packed, "repack plan: forward filters are not prepared");
+        ph[0].push_back(pack_job_conv(w, c->cout, c->cin, c->k, c->packed));
+        if (c->wino) {
+            ph[0].push_back(pack_job_wino_first(w, c->cout, c->cin, c->wino));
+            ph[1].push_back(pack_job_wino_wide(c->cout, c->cin, c->wino));
+        }
+        if (c == &u->conv_in) continue;                       // the network input needs no gradient
+        SISIC_REQUIRE(c->raw_t && c->packed_t, "repack plan: backward filters are not prepared");
+        ph[0].push_back(pack_job_flip(w, c->cout, c->cin, c->k * c->k, c->raw_t));
+        ph[1].push_back(pack_job_conv(c->raw_t, c->cin, c->cout, c->k, c->packed_t));
+        if (c->wino_t) {
+            ph[1].push_back(pack_job_wino_first(c->raw_t, c->cin, c->cout, c->wino_t));
+            ph[2].push_back(pack_job_wino_wide(c->cin, c->cout, c->wino_t));
+        }
+    }
+    for (ResnetW* r : unet_resnets(u)) {
+        ph[0].push_back(pack_job_transpose2d(u->rawp(r->temb_w_idx), r->cout, u->hidden, u->tproj_wt, u->tproj_R, r->temb_off));
+        ph[0].push_back(pack_job_copy(u->rawp(r->temb_b_idx), u->tproj_b + r->temb_off, (size_t)r->cout));
+    }
+    for (AttnW* a : unet_attns(u)) {
+        const int c = a->c;
+        SISIC_REQUIRE(a->qkv_cat && a->qkv_packed && a->qkv_bias && a->qkv_raw_t && a->qkv_packed_t, "repack plan: attention filters are not prepared");
+        const int wi[3] = {a->q_w, a->k_w, a->v_w}, bi[3] = {a->q_b, a->k_b, a->v_b};
+        for (int i = 0; i < 3; ++i) {
+            ph[0].push_back(pack_job_copy(u->rawp(wi[i]), a->qkv_cat + (size_t)i * c * c, (size_t)c * c));
+            ph[0].push_back(pack_job_copy(u->rawp(bi[i]), a->qkv_bias + (size_t)i * c, (size_t)c));
+        }
+        ph[1].push_back(pack_job_conv(a->qkv_cat, 3 * c, c, 1, a->qkv_packed));
+        ph[1].push_back(pack_job_flip(a->qkv_cat, 3 * c, c, 1, a->qkv_raw_t));
+        ph[2].push_back(pack_job_conv(a->qkv_raw_t, c, 3 * c, 1, a->qkv_packed_t));
+    }
+    for (int p = 0; p < 3; ++p) {
+        int blocks = 0;
+        for (PackJob& j : ph[p]) { j.first_block = blocks; blocks += pack_job_blocks(j); }
+        if (tr->repack_dev[p]) { (void)hipFree(tr->repack_dev[p]); tr->repack_dev[p] = nullptr; }
+        SISIC_HIP(hipMalloc(&tr->repack_dev[p], std::max<size_t>(ph[p].size(), 1) * sizeof(PackJob)));
+        SISIC_HIP(hipMemcpy(tr->repack_dev[p], ph[p].data(), ph[p].size() * sizeof(PackJob), hipMemcpyHostToDevice));
+        tr->repack_jobs[p] = (int)ph[p].size();
+        tr->repack_blocks[p] = blocks;
+    }
+    tr->repack_ready = true;
+    return SISIC_OK;
+}
+
+int run_repack_plan(sisic_unet* u, hipStream_t s) {
+    TrainState* tr = u->train.get();
+    for (int p = 0; p < 3; ++p)
+        SISIC_TRY(launch_pack_batch(u->ctx, static_cast<const PackJob*>(tr->repack_dev[p]), tr->repack_jobs[p], tr->repack_blocks[p], s));
+    return SISIC_OK;
+}
+
 int prepare_backward_weights(sisic_unet* u, hipStream_t s) {
     for (ConvW* c : unet_convs(u))
         if (c != &u->conv_in) SISIC_TRY(prepare_backward_conv(u, *c, s));     // the network input needs no gradient
@@ -306,6 +368,8 @@ int sisic_unet_train_end(sisic_unet* u) {
     for (float* p : {tr->grad, tr->adam_m, tr->adam_v, tr->emb, tr->h1, tr->t2, tr->dtproj, tr->wgrad_part, tr->scratch, tr->small,
                      tr->loss_dev, tr->mse_part})
         if (p) (void)hipFree(p);
+    for (void* p : tr->repack_dev)
+        if (p) (void)hipFree(p);
     if (tr->flag_dev) (void)hipFree(tr->flag_dev);
     u->train.reset();
     return SISIC_OK;
@@ -397,9 +461,16 @@ int sisic_unet_optimizer_step(sisic_unet* u, double lr, double beta1, double bet
     tr->step += 1;
     SISIC_TRY(launch_adam(u->ctx, u->raw, tr->grad, tr->adam_m, tr->adam_v, u->raw_floats, lr, beta1, beta2, eps, tr->step,
                           inv_scale, s));
-    // every derived form of the weights follows the update
+    // every derived form of the weights follows the update: three batched launches (repack.hip); the one-launch-per-tensor
+    // route of the load path when the buffers have moved since the job tables were built (SISIC_REPACK_BATCH=0: always)
+    static const bool batch_on = [] { const char* e = std::getenv("SISIC_REPACK_BATCH"); return !e || std::atoi(e) != 0; }();
+    if (batch_on && tr->repack_ready) return run_repack_plan(u, s);
     SISIC_TRY(unet_prepare_all(u, s));
     SISIC_TRY(prepare_backward_weights(u, s));
+    if (batch_on) {
+        SISIC_HIP(hipStreamSynchronize(s));
+        SISIC_TRY(build_repack_plan(u));
+    }
     return SISIC_OK;
 }
 

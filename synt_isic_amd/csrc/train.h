@@ -20,6 +20,25 @@ struct WgradArgs {
 size_t conv_wgrad_scratch_floats(const WgradArgs& a);
 int launch_conv_wgrad(sisic_ctx*, const WgradArgs& a, float* part, size_t part_floats, hipStream_t s);
 int launch_transpose_flip(sisic_ctx*, const float* w, int Cout, int Cin, int KK, float* wt, hipStream_t s);
+
+// repack.hip: one re-layout of one tensor inside a batched launch (pack_batch_kernel)
+struct PackJob {
+    enum Kind : int { COPY = 0, TRANSPOSE2D, FLIP, CONV_PACK, WINO_FIRST, WINO_WIDE };
+    int kind;
+    int a, b, c, d, e;          // shape arguments of the kind's per-element function (see the constructors in repack.hip)
+    const float* src;
+    float* dst;
+    size_t total;               // elements of the job's index space
+    int first_block;            // first workgroup of the launch that works on this job
+};
+int pack_job_blocks(const PackJob& j);
+int launch_pack_batch(sisic_ctx*, const PackJob* dev_jobs, int njobs, int nblocks, hipStream_t s);
+PackJob pack_job_copy(const float* src, float* dst, size_t n);
+PackJob pack_job_transpose2d(const float* in, int rows, int cols, float* out, int out_ld, int out_col0);
+PackJob pack_job_flip(const float* w, int Cout, int Cin, int KK, float* wt);
+PackJob pack_job_conv(const float* w, int Cout, int Cin, int k, float* packed);
+PackJob pack_job_wino_first(const float* w, int Cout, int Cin, float* packed);
+PackJob pack_job_wino_wide(int Cout, int Cin, float* packed);
 int launch_plane_sums(sisic_ctx*, const float* x, int planes, int HW, float* out, hipStream_t s);
 int launch_col_sums(sisic_ctx*, const float* m, int rows, int cols, int ld, float* out, int accumulate, hipStream_t s);
 int launch_copy_cols(sisic_ctx*, const float* src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);

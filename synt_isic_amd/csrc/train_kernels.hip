@@ -14,6 +14,7 @@
 //   * GroupNorm(+SiLU) backward, attention backward (recomputing softmax per head, d = 8), the small linears of the time
 //     embedding, MSE, add_noise and Adam are HBM- or latency-bound vector kernels.
 #include "common.h"
+#include "pack_device.h"
 #include "train.h"
 
 namespace sisic {
@@ -294,10 +295,7 @@ int launch_conv_wgrad(sisic_ctx* ctx, const WgradArgs& a, float* part, size_t pa
 __global__ void transpose_flip_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, float* __restrict__ wt) {
     const size_t n = (size_t)Cout * Cin * KK;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int t = (int)(i % KK);
-        const size_t cc = i / KK;
-        const int ci = (int)(cc % Cin), co = (int)(cc / Cin);
-        wt[((size_t)ci * Cout + co) * KK + (KK - 1 - t)] = w[i];
+        transpose_flip_elem(i, w, Cout, Cin, KK, wt);
     }
 }
 

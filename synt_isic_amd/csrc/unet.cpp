@@ -212,6 +212,7 @@ void reset_attn(AttnW& a) {
 }
 void reset_resnet(ResnetW& r) { reset_conv(r.conv1); reset_conv(r.conv2); reset_conv(r.shortcut); }
 void reset_derived(sisic_unet* u) {
+    if (u->train) u->train->repack_ready = false;       // the job tables of repack.hip name the old buffers
     u->d_freqs = u->w1t = u->w2t = u->tproj_wt = u->tproj_b = nullptr;
     reset_conv(u->conv_in); reset_conv(u->conv_out);
     for (auto& blk : u->down_res) for (auto& r : blk) reset_resnet(r);

@@ -121,6 +121,10 @@ struct TrainState {
     float* loss_dev = nullptr;        // [2]: loss, scratch
     int* flag_dev = nullptr;          // non-finite gradient flag
     float* mse_part = nullptr;
+    // every re-layout of every weight as three batched launches (repack.hip); rebuilt when the derived buffers move
+    void* repack_dev[3] = {nullptr, nullptr, nullptr};     // PackJob tables on the device, one per phase
+    int repack_jobs[3] = {0, 0, 0}, repack_blocks[3] = {0, 0, 0};
+    bool repack_ready = false;
 };
 
 }  // namespace sisic

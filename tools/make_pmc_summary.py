@@ -60,7 +60,8 @@ def main():
         summary[name] = e
         # the dominant kernel family of bench.py's roofline (profile slot "conv3x3_winograd_main"): the stride-1, non-upsampled
         # F(2x2,3x3) launches in their three geometries
-        is_main = (re.search(r"conv_winograd_wide_kernel<", name) or re.search(r"conv_winograd_kernel<1, 8, 8, \d, 16, false>", name))
+        is_main = (re.search(r"conv_winograd_wide_kernel<\d+, \d+, \d, false>", name) or      # (not the image-pair form of the 8x8 level)
+                   re.search(r"conv_winograd_kernel<1, 8, 8, \d, 16, false>", name))
         if is_main:
             main_bytes += (rd + wb) * n
             main_calls += n
