@@ -315,3 +315,15 @@ def test_training_loop_overfits_one_batch_and_fused_step_agrees(synthetic_sd, tm
     m3 = _new_model(ck)
     x = torch.randn(1, 3, 32, 32, generator=g).to(DEV)
     assert torch.equal(m3.eval()(x, 10).sample, m1.eval()(x, 10).sample)
+    # m1's filters were re-laid out by the batched launches that follow every optimizer step (repack.hip), m3's by the load
+    # path's one launch per tensor: the same bits forward (above) and through the backward-data / weight-gradient pass
+    from synt_isic_amd.train import HipAdam, mse_loss
+    t = torch.tensor([10], device=DEV)
+    target = torch.randn(1, 3, 32, 32, generator=g).to(DEV)
+    grads = []
+    for m in (m1, m3):
+        m.train()
+        HipAdam(m.parameters(), lr=1e-4).zero_grad()
+        mse_loss(m(x, t).sample, target).backward()
+        grads.append(m.grads())
+    assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
