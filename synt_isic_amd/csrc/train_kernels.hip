@@ -46,11 +46,20 @@ __device__ __forceinline__ float silu_grad(float u) {
 __device__ __forceinline__ float silu_fwd(float u) { return u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }   // as the forward kernels
 
 // ================================================================ convolution backward-weight ======================
-// Workgroup = 4 waves: 64 output channels x 64 input channels x KK taps of dW, summed over this workgroup's share of the
-// pixel blocks (TR x TC output pixels each).  Wave w owns the 32x32 block (co half w & 1, ci half w >> 1) for all taps:
-// KK accumulators of 16 registers.  Per pixel block: dy tile [64][P] and the input halo [64][IH*IW] (prologue applied,
-// zero padding after it, concat / nearest-2x index maps as in the forward) are staged in LDS; a k-step of the MFMA is two
-// neighbouring pixels; the A fragment (dy) is shared by the KK taps, the B fragment is the halo read at the tap's offset.
+// Workgroup = 64 output channels x 64 input channels x KK taps of dW, summed over this workgroup's share of the pixel
+// blocks (TR x TC output pixels each).  Four waves: wave (mt, nt) owns the 32x32 block (co half mt, ci half nt) for all
+// taps -- KK accumulators of 16 registers, two workgroups per CU.  (Splitting the nine taps over two wave groups, 80
+// accumulator registers and four waves per SIMD, was tried: the prefetch does not fit 128 registers beside them.)  Per pixel block: dy tile [64][P] and the input halo [64][IH*IW]
+// (prologue applied, zero padding after it, concat / nearest-2x index maps as in the forward) are staged in LDS; a k-step
+// of the MFMA is two neighbouring pixels; the A fragment (dy) is shared by a wave's taps, the B fragment is the halo read
+// at the tap's offset.
+//   * the halo loads of block i+1 are issued before the MFMAs of block i and consumed after them (register prefetch);
+//   * the partial tile leaves through LDS, one 32x32xKK quadrant at a time, so that a wave stores runs of 288 contiguous
+//     floats instead of 144 scattered dwords per lane.
+// Measured against round 2's first version (load, stage, compute one block after the other; scattered stores), batch 32 at
+// 64x64: 1x1 74 -> 43 us per launch; 3x3 unchanged within 3 % -- those launches are bounded by their K-split slabs (512
+// workgroups x a 147-KB tile = 75 MB written and re-read per weight gradient of a 64-channel layer), not by load latency.
+// Every (co, ci, tap) element still sums its pixels in the same order: the gradients keep their bits.
 struct WgradParams {
     const float* in0; const float* in1; int c0, c1;
     int B, Hin, Win, ups, Hc, Wc, Hout, Wout;
@@ -69,12 +78,23 @@ struct WgradGeom {
     static constexpr int HEL = IH * IW;
     static constexpr int CHS = HEL | 1;                     // odd channel stride: the 32 lanes of a fragment read hit 32 banks
     static constexpr int DYS = P + 1;
-    static constexpr size_t LDS_BYTES = (size_t)(64 * CHS + 64 * DYS) * sizeof(float);
+    static constexpr int TG = 1;                            // tap groups = wave groups (2 was tried for 3x3: 8 waves x 80 accumulators do not fit 128 registers beside the prefetch)
+    static constexpr int NW = 4 * TG, NTHR = 64 * NW;
+    static constexpr int TAPS = (KK + TG - 1) / TG;         // taps per wave: 5 (groups of 5 and 4) | 1
+    static constexpr int HCH = 64 / NW;                     // halo channels staged per wave
+    static constexpr int HPASS = (HEL + 63) / 64;
+    static constexpr int DY_CO_STEP = NTHR / P;             // channels covered per pass of the dy staging
+    static constexpr int DY_PASSES = 64 / DY_CO_STEP;
+    static constexpr int STAGE_FLOATS = 64 * CHS + 64 * DYS;
+    static constexpr int QUAD_FLOATS = 32 * 32 * KK;        // one quadrant of the partial tile, [co][ci][tap]
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)(STAGE_FLOATS > QUAD_FLOATS ? STAGE_FLOATS : QUAD_FLOATS);
     static_assert(P % 2 == 0 && TC % 2 == 0, "two pixels of a row per MFMA k-step");
+    static_assert(NTHR % P == 0 && 64 % DY_CO_STEP == 0, "dy staging plan");
+    static_assert(HPASS <= 8, "halo valid mask");
 };
 
 template <int KS, int STRIDE, int TR, int TC>
-__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p) {
+__global__ void __launch_bounds__((WgradGeom<KS, STRIDE, TR, TC>::NTHR), 2) conv_wgrad_kernel(const WgradParams p) {
     using G = WgradGeom<KS, STRIDE, TR, TC>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const aL = smem;                     // [64 ci][CHS]
@@ -86,14 +106,15 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     const int ks = work;
     const int co0 = co_t * 64, ci0 = ci_t * 64;
     const int Cin = p.c0 + p.c1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int mt = wave & 1, nt = wave >> 1;
+    const int tg = wave >> 2, mt = wave & 1, nt = (wave >> 1) & 1;
     const int HWin = p.Hin * p.Win, HWout = p.Hout * p.Wout;
 
-    f32x16 acc[G::KK];
+    f32x16 acc[G::TAPS];
 #pragma unroll
-    for (int t = 0; t < G::KK; ++t)
+    for (int t = 0; t < G::TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
@@ -102,105 +123,140 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(const WgradParams p)
     const float* d_base = dL + (mt * 32 + l31) * G::DYS + half;
 
     // ---- staging plans, invariant over the pixel blocks (no division inside the block loop)
-    // dy tile: a thread keeps one pixel of the block (lane -> pixel when P = 64) and walks the output channels
-    static_assert(256 % G::P == 0 || G::P % 256 == 0, "dy staging plan");
-    constexpr int DY_CO_STEP = (G::P <= 256) ? 256 / G::P : 1;          // channels covered per pass
-    constexpr int DY_PASSES = (64 * G::P) / 256;
-    const int dpx = tid % G::P, dco = tid / G::P;                       // P >= 256 is not instantiated (P is 32 or 64)
+    const int dpx = tid % G::P, dco = tid / G::P;          // dy tile: a thread keeps one pixel and walks the output channels
     const int dty = dpx / TC, dtx = dpx % TC;
-    // halo: wave w stages channels w*16 .. w*16+15; lanes sweep the HEL elements of a channel in HPASS passes
-    constexpr int HPASS = (G::HEL + 63) / 64;
-    int hyy[HPASS], hxx[HPASS];
+    int hyy[G::HPASS], hxx[G::HPASS];                      // halo: a wave stages HCH channels, its lanes sweep a channel's HEL elements
 #pragma unroll
-    for (int q = 0; q < HPASS; ++q) {
+    for (int q = 0; q < G::HPASS; ++q) {
         const int r = min(lane + 64 * q, G::HEL - 1);
         hyy[q] = r / G::IW;
         hxx[q] = r % G::IW;
     }
 
-    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+    // one pixel block's input halo in flight: raw values, no prologue yet.  (The dy tile is NOT prefetched: its 16 values per
+    // thread beside 144 accumulators spill, and a spill reload inside the MFMA loop waits for vmcnt(0) -- i.e. for the very
+    // loads the prefetch wanted to overlap.  Its loads are issued at the top of stage() and land under the halo's prologue.)
+    struct Pre {
+        float hv[G::HCH][G::HPASS];
+        unsigned hmask;              // bit q: halo element of pass q lies inside the image
+        int b, oy0, ox0;
+    };
+    auto prefetch = [&](int blk, Pre& r) {
         int t = blk;
         const int tx = t % p.tiles_x; t /= p.tiles_x;
         const int ty = t % p.tiles_y;
         const int b = t / p.tiles_y;
         const int oy0 = ty * TR, ox0 = tx * TC;
-        __syncthreads();                          // the previous block's fragments have been read
-        // ---- dy tile: 64 channels x P pixels, zero outside the image / past Cout
-        {
-            const int oy = oy0 + dty, ox = ox0 + dtx;
-            const bool pin = oy < p.Hout && ox < p.Wout;
-            const float* src = p.dy + (size_t)b * p.Cout * HWout + (size_t)min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
-            float v[DY_PASSES];
+        r.b = b; r.oy0 = oy0; r.ox0 = ox0;
+        const int iy0 = oy0 * STRIDE - G::PAD, ix0 = ox0 * STRIDE - G::PAD;
+        int goff[G::HPASS];
+        r.hmask = 0;
 #pragma unroll
-            for (int k = 0; k < DY_PASSES; ++k) {
-                const int co = dco + k * DY_CO_STEP;
-                v[k] = src[(size_t)min(co0 + co, p.Cout - 1) * HWout];
-            }
-#pragma unroll
-            for (int k = 0; k < DY_PASSES; ++k) {
-                const int co = dco + k * DY_CO_STEP;
-                dL[co * G::DYS + dpx] = (pin && (co0 + co) < p.Cout) ? v[k] : 0.0f;
-            }
+        for (int q = 0; q < G::HPASS; ++q) {
+            const int y = iy0 + hyy[q], x = ix0 + hxx[q];
+            const bool ok = (lane + 64 * q) < G::HEL && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
+            r.hmask |= (ok ? 1u : 0u) << q;
+            goff[q] = (min(max(y, 0), p.Hc - 1) >> p.ups) * p.Win + (min(max(x, 0), p.Wc - 1) >> p.ups);
         }
-        // ---- input halo: 64 channels x IH x IW with the forward's prologue, zero padding AFTER it
-        {
-            const int iy0 = oy0 * STRIDE - G::PAD, ix0 = ox0 * STRIDE - G::PAD;
-            int goff[HPASS];
-            bool gok[HPASS];
 #pragma unroll
-            for (int q = 0; q < HPASS; ++q) {
-                const int y = iy0 + hyy[q], x = ix0 + hxx[q];
-                gok[q] = (lane + 64 * q) < G::HEL && y >= 0 && y < p.Hc && x >= 0 && x < p.Wc;
-                goff[q] = (min(max(y, 0), p.Hc - 1) >> p.ups) * p.Win + (min(max(x, 0), p.Wc - 1) >> p.ups);
+        for (int j = 0; j < G::HCH; ++j) {
+            const int cc = min(ci0 + wave * G::HCH + j, Cin - 1);
+            const float* plane = cc < p.c0 ? p.in0 + ((size_t)b * p.c0 + cc) * HWin
+                                           : p.in1 + ((size_t)b * p.c1 + (cc - p.c0)) * HWin;
+#pragma unroll
+            for (int q = 0; q < G::HPASS; ++q) r.hv[j][q] = plane[goff[q]];
+        }
+    };
+    auto stage = [&](const Pre& r) {
+        // dy tile: 64 channels x P pixels, zero outside the image / past Cout (requested here, written below)
+        const int oy = r.oy0 + dty, ox = r.ox0 + dtx;
+        const bool pin = oy < p.Hout && ox < p.Wout;
+        const float* dsrc = p.dy + (size_t)r.b * p.Cout * HWout + (size_t)min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
+        float dyv[G::DY_PASSES];
+#pragma unroll
+        for (int k = 0; k < G::DY_PASSES; ++k) dyv[k] = dsrc[(size_t)min(co0 + dco + k * G::DY_CO_STEP, p.Cout - 1) * HWout];
+        // input halo: 64 channels x IH x IW with the forward's prologue, zero padding AFTER it
+#pragma unroll
+        for (int j = 0; j < G::HCH; ++j) {
+            const int ci = wave * G::HCH + j;
+            const int c = ci0 + ci;
+            const int cc = min(c, Cin - 1);
+            float sc = 1.0f, sh = 0.0f;
+            if (p.gn_scale) {
+                sc = p.gn_scale[(size_t)r.b * Cin + cc];
+                sh = p.gn_shift[(size_t)r.b * Cin + cc];
             }
-#pragma unroll 4
-            for (int j = 0; j < 16; ++j) {
-                const int ci = wave * 16 + j;
-                const int c = ci0 + ci;
-                const int cc = min(c, Cin - 1);
-                const float* plane = cc < p.c0 ? p.in0 + ((size_t)b * p.c0 + cc) * HWin
-                                               : p.in1 + ((size_t)b * p.c1 + (cc - p.c0)) * HWin;
-                float sc = 1.0f, sh = 0.0f;
+#pragma unroll
+            for (int q = 0; q < G::HPASS; ++q) {
+                float v = r.hv[j][q];
                 if (p.gn_scale) {
-                    sc = p.gn_scale[(size_t)b * Cin + cc];
-                    sh = p.gn_shift[(size_t)b * Cin + cc];
+                    v = v * sc + sh;
+                    if (p.gn_silu) v = silu_fwd(v);
                 }
-                float hv[HPASS];
-#pragma unroll
-                for (int q = 0; q < HPASS; ++q) hv[q] = plane[goff[q]];
-#pragma unroll
-                for (int q = 0; q < HPASS; ++q) {
-                    float v = hv[q];
-                    if (p.gn_scale) {
-                        v = v * sc + sh;
-                        if (p.gn_silu) v = silu_fwd(v);
-                    }
-                    if ((lane + 64 * q) < G::HEL) aL[ci * G::CHS + lane + 64 * q] = (gok[q] && c < Cin) ? v : 0.0f;
-                }
+                if ((lane + 64 * q) < G::HEL) aL[ci * G::CHS + lane + 64 * q] = (((r.hmask >> q) & 1u) && c < Cin) ? v : 0.0f;
             }
         }
-        __syncthreads();
-        // ---- P/2 k-steps x KK taps
-#pragma unroll 4
+#pragma unroll
+        for (int k = 0; k < G::DY_PASSES; ++k) {
+            const int co = dco + k * G::DY_CO_STEP;
+            dL[co * G::DYS + dpx] = (pin && (co0 + co) < p.Cout) ? dyv[k] : 0.0f;
+        }
+    };
+    // P/2 k-steps x this wave's taps [T0, T0 + NT): compile-time tap offsets
+    auto compute = [&](auto t0_tag, auto nt_tag) {
+        constexpr int T0 = decltype(t0_tag)::value, NTAP = decltype(nt_tag)::value;
+#pragma unroll 2
         for (int kp = 0; kp < G::P / 2; ++kp) {
             const int py = (2 * kp) / TC, pxx = (2 * kp) % TC;        // this lane's pixel is (py, pxx + half)
             const float a = d_base[2 * kp];
 #pragma unroll
-            for (int t = 0; t < G::KK; ++t) {
+            for (int tt = 0; tt < NTAP; ++tt) {
+                constexpr int dummy = 0; (void)dummy;
+                const int t = T0 + tt;
                 const float bv = a_base[(py * STRIDE + t / KS) * G::IW + pxx * STRIDE + t % KS];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[t], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[tt], 0, 0, 0);
             }
         }
+    };
+
+    Pre pre;
+    if (blk_lo < blk_hi) prefetch(blk_lo, pre);
+    for (int blk = blk_lo; blk < blk_hi; ++blk) {
+        __syncthreads();                          // the previous block's fragments have been read
+        stage(pre);
+        __syncthreads();
+        if (blk + 1 < blk_hi) prefetch(blk + 1, pre);      // in flight during the MFMAs below
+        if constexpr (G::TG == 1) {
+            compute(std::integral_constant<int, 0>{}, std::integral_constant<int, G::KK>{});
+        } else {
+            if (tg == 0) compute(std::integral_constant<int, 0>{}, std::integral_constant<int, G::TAPS>{});
+            else compute(std::integral_constant<int, G::TAPS>{}, std::integral_constant<int, G::KK - G::TAPS>{});
+        }
     }
-    // ---- partial dW of this slice: row = co, column (lane) = ci
+
+    // ---- partial dW of this slice, one (co half, ci half) quadrant at a time through LDS: [32 co][32 ci][KK]
     float* const dst = p.part + (size_t)ks * p.Cout * Cin * G::KK;
-    const int ci = ci0 + nt * 32 + l31;
+    float* const quad = smem;
+    const int t0 = tg * G::TAPS, ntap = min(G::TAPS, G::KK - t0);
+#pragma unroll 1
+    for (int qd = 0; qd < 4; ++qd) {
+        const int qm = qd & 1, qn = qd >> 1;
+        __syncthreads();                          // staging buffers (first round) / the previous quadrant have been read
+        if (mt == qm && nt == qn) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co0 + mt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        if (co < p.Cout && ci < Cin) {
+            for (int r = 0; r < 16; ++r) {
+                const int co_l = 8 * (r >> 2) + 4 * half + (r & 3);
 #pragma unroll
-            for (int t = 0; t < G::KK; ++t) dst[((size_t)co * Cin + ci) * G::KK + t] = acc[t][r];
+                for (int tt = 0; tt < G::TAPS; ++tt)
+                    if (tt < ntap) quad[(co_l * 32 + l31) * G::KK + t0 + tt] = acc[tt][r];
+            }
+        }
+        __syncthreads();
+        const int cob = co0 + qm * 32, cib = ci0 + qn * 32;
+        for (int e = tid; e < G::QUAD_FLOATS; e += G::NTHR) {
+            const int co_l = e / (32 * G::KK), rem = e % (32 * G::KK);
+            const int ci_l = rem / G::KK;
+            if (cob + co_l < p.Cout && cib + ci_l < Cin) dst[((size_t)(cob + co_l) * Cin + cib) * G::KK + rem] = quad[e];
         }
     }
 }
@@ -226,7 +282,7 @@ static int launch_wgrad_cfg(sisic_ctx* ctx, WgradParams& p, hipStream_t s) {
     static std::atomic<uint64_t> lds_opt_in{0};
     SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)G::LDS_BYTES, lds_opt_in));
     const int64_t nwg = (int64_t)p.n_co_tiles * p.n_ci_tiles * p.ksplit;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), G::LDS_BYTES, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(G::NTHR), G::LDS_BYTES, s, p);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
@@ -277,9 +333,7 @@ int launch_conv_wgrad(sisic_ctx* ctx, const WgradArgs& a, float* part, size_t pa
         } else if (a.stride == 2) {
             if (p.Wout > 8) SISIC_TRY((launch_wgrad_cfg<3, 2, 2, 16>(ctx, p, s)));
             else SISIC_TRY((launch_wgrad_cfg<3, 2, 4, 8>(ctx, p, s)));
-        } else if (p.Wout > 16) {
-            SISIC_TRY((launch_wgrad_cfg<3, 1, 2, 32>(ctx, p, s)));
-        } else if (p.Wout > 8) {
+        } else if (p.Wout > 8) {        // (2 x 32 pixel blocks for wide images were measured: 34-float halo rows, 21 spilled registers, 3 % slower)
             SISIC_TRY((launch_wgrad_cfg<3, 1, 4, 16>(ctx, p, s)));
         } else {
             SISIC_TRY((launch_wgrad_cfg<3, 1, 8, 8>(ctx, p, s)));
