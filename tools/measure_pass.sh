@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 measurement pass of the committed library: full -m gpu suite (measured-error log), default bench (full T=1000),
+# measurement pass of the committed library (run through gpurun): full -m gpu suite (measured-error log), default bench (full T=1000),
 # rocprofv3 kernel statistics of the same command, three PMC passes
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
