@@ -206,6 +206,19 @@ def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: t
                         steps_done=done.value, cancelled=cancelled)
 
 
+def segment_bounds(T: int, seg: int, per_step: int) -> List[int]:
+    """Step boundaries of the segments a streamed run is cut into (``NoiseStream``): ``seg`` steps each, except that a run
+    whose segment is a noticeable amount of RNG (more than 8 M normals: 64 images at 64x64 draw 50 M per 64 steps) starts
+    with 4, 8, 16, ... steps, so that the GPU starts after a few milliseconds instead of a whole segment's worth.  The
+    draws do not depend on the segmentation.  For one 128x128 image the three extra ``sisic_sample`` calls of a T=50 run
+    cost 70 ms against 12 ms of RNG saved (measured), hence the threshold."""
+    bounds, n = [0], (4 if per_step * seg > 8_000_000 else seg)
+    while bounds[-1] < T:
+        bounds.append(min(T, bounds[-1] + min(n, seg)))
+        n *= 2
+    return bounds
+
+
 def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch.Tensor, ns: NoiseStream,
                   return_trajectory: bool, cancel_flag: Optional[C.c_int]) -> SampleResult:
     lib = _lib.load()
@@ -215,14 +228,7 @@ def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch
     T = ts.numel()
     coef = scheduler.coefficient_table().contiguous()
     needs = (coef[:, 4] != 0).to(torch.int64)                   # 1 where the step adds noise
-    # Segment boundaries: short segments first (4, 8, 16, ... steps), so that the GPU starts after a few milliseconds of RNG
-    # instead of a whole segment's worth (64 steps x 64 images = 50 M normals); the draws do not depend on the segmentation.
-    # (only when a whole segment is a noticeable amount of RNG: for one 128x128 image the three extra sisic_sample calls of a
-    #  T=50 run cost 70 ms against 12 ms of RNG saved -- measured)
-    bounds, n = [0], (4 if B * Cc * H * W * ns.seg > 8_000_000 else ns.seg)
-    while bounds[-1] < T:
-        bounds.append(min(T, bounds[-1] + min(n, ns.seg)))
-        n *= 2
+    bounds = segment_bounds(T, ns.seg, B * Cc * H * W)
     counts = [int(needs[a:b].sum()) for a, b in zip(bounds[:-1], bounds[1:])]
     x = x_T.to(torch.float32).contiguous().clone()
     traj = torch.empty((T, B, Cc, H, W), dtype=torch.float32, device=dev) if return_trajectory else None

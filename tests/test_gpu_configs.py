@@ -151,3 +151,32 @@ def test_nccl_world1_gather_and_max():
             sdist.gather_images(imgs[:10], 64, dst=0)              # a shard of the wrong length is refused
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_line_contract():
+    """`python bench.py` (short run, no CPU leg) as the driver starts it: ONE JSON line on stdout carrying the metric of
+    BASELINE.json, a roofline object whose fraction is the executed-MFMA fraction (<= 1 by construction) and the
+    host-inclusive leg; the HIP-event per-launch figures are self-consistent."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"].startswith("images/sec at 3x64x64 T=1000") and base["metric"].startswith("images/sec at 3")
+    assert d["unit"] == "images/sec"
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] == "weak"
+    assert abs(d["value"] - 64.0 / (d["ms_per_step"] * 1e-3 * 1000)) < 1e-6 * d["value"]       # images/sec of a T=1000 run
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    assert 0.3 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
+    assert rf["launches_per_step"] == 31.0 and rf["traffic"] is not None and "traffic_source" in rf
+    assert d["e2e_images_per_sec"] > 0.0        # (over 6 steps the host-inclusive leg is mostly its fixed costs)
+

@@ -277,3 +277,18 @@ def test_color_postprocessing_matches_oracle_bit_exact(tmp_path):
     assert s.load_color_statistics(str(tmp_path / "missing.json")) == 0
     (tmp_path / "color_statistics.json").write_text(json.dumps({"NV": stats, "MEL": only_mean}))
     assert s.load_color_statistics(str(tmp_path / "color_statistics.json")) == 2 and "NV" in s.color_statistics
+
+
+def test_streamed_segments_cover_the_run_and_ramp_only_for_big_batches():
+    """sampler.segment_bounds: contiguous segments over [0, T], none longer than the stream's buffers; a batch whose segment
+    is a lot of RNG starts with 4, 8, 16, ... steps, a single image does not."""
+    from synt_isic_amd.sampler import segment_bounds
+    for T in (1, 3, 4, 50, 64, 65, 130, 1000):
+        for seg in (1, 8, 64):
+            for per in (3 * 128 * 128, 64 * 3 * 64 * 64):
+                b = segment_bounds(T, seg, per)
+                assert b[0] == 0 and b[-1] == T and all(0 < y - x <= seg for x, y in zip(b[:-1], b[1:]))
+    assert segment_bounds(1000, 64, 64 * 3 * 64 * 64)[:6] == [0, 4, 12, 28, 60, 124]
+    assert segment_bounds(50, 64, 3 * 128 * 128) == [0, 50]
+    assert segment_bounds(130, 64, 3 * 128 * 128) == [0, 64, 128, 130]
+
