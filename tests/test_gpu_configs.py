@@ -178,5 +178,7 @@ def test_bench_line_contract():
     assert 0.3 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
     assert rf["launches_per_step"] == 31.0 and rf["traffic"] is not None and "traffic_source" in rf
+    # HIP-event brackets against the committed rocprofv3 kernel durations of the same command: within 10 % (other box, gaps)
+    assert rf["rocprofv3_avg_launch_us"] and abs(rf["avg_launch_us"] / rf["rocprofv3_avg_launch_us"] - 1.0) < 0.10
     assert d["e2e_images_per_sec"] > 0.0        # (over 6 steps the host-inclusive leg is mostly its fixed costs)
 
