@@ -296,6 +296,8 @@ static int wgrad_ksplit(const WgradArgs& a, int Hout, int Wout) {
     return std::max(1, std::min(nblocks_min, cdiv(256, tiles)));
 }
 
+#include "wgrad_winograd.inc"
+
 static void wgrad_out_dims(const WgradArgs& a, int* Hout, int* Wout) {
     const int Hc = a.Hin << (a.ups ? 1 : 0), Wc = a.Win << (a.ups ? 1 : 0), pad = a.ksize / 2;
     *Hout = (Hc + 2 * pad - a.ksize) / a.stride + 1;
@@ -305,7 +307,9 @@ static void wgrad_out_dims(const WgradArgs& a, int* Hout, int* Wout) {
 size_t conv_wgrad_scratch_floats(const WgradArgs& a) {
     int Hout, Wout;
     wgrad_out_dims(a, &Hout, &Wout);
-    return (size_t)wgrad_ksplit(a, Hout, Wout) * a.Cout * (a.c0 + a.c1) * a.ksize * a.ksize;
+    const size_t direct = (size_t)wgrad_ksplit(a, Hout, Wout) * a.Cout * (a.c0 + a.c1) * a.ksize * a.ksize;
+    if (!wgrad_wino_applicable(a)) return direct;
+    return std::max(direct, ((size_t)wgrad_wino_ksplit(a, Hout, Wout) + 1) * 16 * a.Cout * (a.c0 + a.c1));      // slabs + their sum
 }
 
 int launch_conv_wgrad(sisic_ctx* ctx, const WgradArgs& a, float* part, size_t part_floats, hipStream_t s) {
@@ -326,12 +330,17 @@ int launch_conv_wgrad(sisic_ctx* ctx, const WgradArgs& a, float* part, size_t pa
     const size_t n = (size_t)a.Cout * Cin * a.ksize * a.ksize;
     SISIC_REQUIRE((size_t)p.ksplit * n <= part_floats, "conv_wgrad: scratch too small");
     const double flops = 2.0 * a.B * a.Cout * (double)p.Hout * p.Wout * Cin * a.ksize * a.ksize;
+    static const bool wino_on = [] { const char* e = std::getenv("SISIC_WGRAD_WINOGRAD"); return !e || std::atoi(e) != 0; }();
     {
         ProfileScope prof(ctx, s, PK_OTHER, 4.0 * a.B * ((double)Cin * a.Hin * a.Win + (double)a.Cout * p.Hout * p.Wout) + 4.0 * n, flops);
         if (a.ksize == 1) {
             // flat pixel rows: the image is one row of H*W pixels
             p.Hin = 1; p.Win = a.Hin * a.Win; p.Hc = 1; p.Wc = p.Win; p.Hout = 1; p.Wout = p.Win;
             SISIC_TRY((launch_wgrad_cfg<1, 1, 1, 64>(ctx, p, s)));
+        } else if (a.stride == 1 && wino_on) {
+            // Winograd-domain form (wgrad_winograd.inc): its own reduction, so it returns here
+            SISIC_REQUIRE(((size_t)wgrad_wino_ksplit(a, p.Hout, p.Wout) + 1) * 16 * a.Cout * Cin <= part_floats, "conv_wgrad: scratch too small");
+            return launch_wgrad_wino(ctx, p, a, s);
         } else if (a.stride == 2) {
             if (p.Wout > 8) SISIC_TRY((launch_wgrad_cfg<3, 2, 2, 16>(ctx, p, s)));
             else SISIC_TRY((launch_wgrad_cfg<3, 2, 4, 8>(ctx, p, s)));
