@@ -318,7 +318,8 @@ static int wgrad_ksplit(const WgradArgs& a, int Hout, int Wout) {
     const int nblocks_min = a.B * cdiv(Hout, 8) * cdiv(Wout, 8);           // 64-pixel blocks
     // one workgroup per CU: measured level with two (26.8 vs 26.9 ms per step at batch 32, 64x64) and ahead at the
     // reference's batch 2, 128x128 (25.9 vs 26.9) -- half the partial slabs to write and re-read
-    return std::max(1, std::min(nblocks_min, cdiv(256, tiles)));
+    // (1x1: 16 accumulator registers, four workgroups fit a CU -- more, smaller slices: 61 -> 43 us per launch)
+    return std::max(1, std::min(nblocks_min, cdiv(a.ksize == 1 ? 1024 : 256, tiles)));
 }
 
 #include "wgrad_winograd.inc"
