@@ -425,6 +425,20 @@ __global__ void col_sum_kernel(const float* __restrict__ m, int rows, int cols, 
     out[c] = accumulate ? out[c] + s : s;
 }
 
+// two matrices at once (GroupNorm backward: dgamma and dbeta over the batch): same per-column order as col_sum_kernel
+__global__ void col_sum2_kernel(const float* __restrict__ ma, const float* __restrict__ mb, int rows, int cols,
+                                float* __restrict__ outa, float* __restrict__ outb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float sa = 0.0f, sb = 0.0f;
+    for (int r = 0; r < rows; ++r) {
+        sa += ma[(size_t)r * cols + c];
+        sb += mb[(size_t)r * cols + c];
+    }
+    outa[c] = sa;
+    outb[c] = sb;
+}
+
 int launch_col_sums(sisic_ctx*, const float* m, int rows, int cols, int ld, float* out, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(col_sum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, m, rows, cols, ld, out, accumulate);
     SISIC_HIP(hipGetLastError());
@@ -519,8 +533,8 @@ int launch_gn_bwd(sisic_ctx* ctx, const float* da, const float* in0, int c0, con
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C), dim3(256), 0, s, da, in0, c0, in1, c1, HW, groups, scale, shift, mean_rstd,
                        gamma, silu, sumA, sumB, g0, g1);
     SISIC_HIP(hipGetLastError());
-    SISIC_TRY(launch_col_sums(ctx, sumB, B, C, C, dgamma, 0, s));
-    SISIC_TRY(launch_col_sums(ctx, sumA, B, C, C, dbeta, 0, s));
+    hipLaunchKernelGGL(col_sum2_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, sumB, sumA, B, C, dgamma, dbeta);
+    SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
 

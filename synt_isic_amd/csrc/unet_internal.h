@@ -112,6 +112,8 @@ struct TrainState {
     size_t emb_cap = 0, h1_cap = 0, t2_cap = 0;
     float* dtproj = nullptr;          // [B, tproj_R] gradient of the fused time_emb_proj outputs
     size_t dtproj_cap = 0;
+    float* garena = nullptr;          // activation gradients of one backward pass: one block, zero-filled once
+    size_t garena_cap = 0, garena_used = 0;
     float* wgrad_part = nullptr;      // K-split partial weight gradients
     size_t wgrad_part_cap = 0;
     float* scratch = nullptr;         // data-gradient scratch [B, Cin, H, W] of the widest layer
