@@ -592,7 +592,8 @@ int launch_add_inplace(sisic_ctx*, float* dst, const float* src, size_t n, hipSt
 // One workgroup per (sample, head), d = 8.  q,k,v,dO of the head in LDS ([N][8] rows).  Softmax is recomputed:
 //   pass A (thread = query i):  m_i, l_i (online), D_i = dO_i . O_i,  dQ_i = scale * sum_j P_ij (dO_i . v_j - D_i) k_j
 //   pass B (thread = key j):    dV_j = sum_i P_ij dO_i,  dK_j = scale * sum_i P_ij (dO_i . v_j - D_i) q_i
-// P_ij = exp(scale q_i . k_j - m_i) / l_i.  No atomics: every output row has one owner.
+// P_ij = exp(scale q_i . k_j - m_i) / l_i.  No atomics: every output row has one owner.  exp = v_exp_f32 (__expf), as in the
+// forward kernel: the accurate expf is ~15 vector instructions of the ~40 per (query, key) pair and pass.
 constexpr int ATB_THREADS = 256;
 
 __global__ void __launch_bounds__(ATB_THREADS)
@@ -629,7 +630,7 @@ attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
 #pragma unroll
             for (int d = 0; d < 8; ++d) sc += q[d] * ks_[j * 8 + d];
             const float mn = fmaxf(m, sc);
-            l = l * expf(m - mn) + expf(sc - mn);
+            l = l * __expf(m - mn) + __expf(sc - mn);
             m = mn;
         }
         float D = 0.0f;
@@ -641,7 +642,7 @@ attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
             float sc = 0.0f, dp = 0.0f;
 #pragma unroll
             for (int d = 0; d < 8; ++d) { sc += q[d] * ks_[j * 8 + d]; dp += g[d] * vs[j * 8 + d]; }
-            const float dsij = expf(sc - m) * il * (dp - D);
+            const float dsij = __expf(sc - m) * il * (dp - D);
 #pragma unroll
             for (int d = 0; d < 8; ++d) dq[d] += dsij * ks_[j * 8 + d];
         }
@@ -660,7 +661,7 @@ attention_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
             float sc = 0.0f, dp = 0.0f;
 #pragma unroll
             for (int d = 0; d < 8; ++d) { sc += qs[i * 8 + d] * k[d]; dp += gs[i * 8 + d] * v[d]; }
-            const float pij = expf(sc - ms[i]) * ls[i];
+            const float pij = __expf(sc - ms[i]) * ls[i];
             const float dsij = pij * (dp - ds[i]);
 #pragma unroll
             for (int d = 0; d < 8; ++d) { dv[d] += pij * gs[i * 8 + d]; dk[d] += dsij * qs[i * 8 + d]; }
