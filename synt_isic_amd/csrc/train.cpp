@@ -238,6 +238,10 @@ struct Bwd {
             a.w_packed = packed_t; a.Cout = Cin;
             a.w_winograd = (op.stride == 1 && !op.qkv_of && u->use_winograd) ? c.wino_t : nullptr;
             a.out = da;
+            if (u->latency_mode) {           // the forward's small-batch tile choices (unet.cpp, Fwd::conv) for the data gradient
+                if (c.k == 3 && op.stride == 1 && a.w_winograd && Cin > 4 && Ho >= 12 && Wo >= 12) a.tile_cfg = 79;
+                else if (c.k == 1) a.tile_cfg = 22;
+            }
             SISIC_TRY(launch_conv2d(u->ctx, a, s));
         }
         float* g0 = nullptr;

@@ -196,6 +196,31 @@ def test_unet_gradients_match_autograd_over_the_oracle(synthetic_sd, batch, refe
     assert all(torch.equal(again[n], grads[n]) for n in grads)
 
 
+def test_unet_gradients_in_latency_mode(synthetic_sd, batch, reference):
+    """The reference trains with batch 2 (train_diffusion.py:59): set_latency_mode picks the small-batch tilings for the
+    forward AND the data-gradient convolutions (K-split Winograd, 64-pixel 1x1 tiles).  Same parity bar as the default mode."""
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    from synt_isic_amd.train import HipAdam, mse_loss
+    images, noise, timesteps = (t.to(DEV) for t in batch)
+    ref_loss, ref_grads, ref_pred = reference
+    model = _new_model(synthetic_sd).set_latency_mode(True)
+    scheduler = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
+    optimizer = HipAdam(model.parameters(), lr=1e-4)
+    model.train()
+    noise_pred = model(scheduler.add_noise(images, noise, timesteps), timesteps).sample
+    assert (noise_pred.cpu() - ref_pred).abs().max().item() <= 2e-4
+    loss = mse_loss(noise_pred, noise)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    grads = model.grads()
+    worst = max((grads[n] - r).abs().max().item() / max(1.0, r.abs().max().item()) for n, r in ref_grads.items())
+    assert worst <= 1e-4, worst
+    rel = sorted((grads[n] - r).abs().max().item() / r.abs().max().item() for n, r in ref_grads.items()
+                 if r.abs().max().item() > 1e-8)
+    assert rel[len(rel) // 2] <= 1e-3 and rel[-1] <= 5e-2, (rel[len(rel) // 2], rel[-1])
+
+
 def test_unet_gradients_at_a_ragged_resolution(synthetic_sd):
     """The same comparison at B=3, 3x40x56 (20x28 / 10x14 / 5x7 below): ragged tiles in every backward kernel, the direct
     convolution kernels at the small levels, attention over 280 and 35 tokens."""

@@ -23,11 +23,13 @@ from synt_isic_amd.unet import HipUNet2DModel  # noqa: E402
 from synt_isic_amd.weights import synthetic_unet_state_dict  # noqa: E402
 
 
-def run(B, size, steps):
+def run(B, size, steps, latency=False):
     dev = torch.device("cuda")
     m = HipUNet2DModel()
     m.load_state_dict(synthetic_unet_state_dict())
     m = m.to(dev)
+    if latency:
+        m.set_latency_mode(True)        # small-batch tile choices (the reference trains with batch 2)
     sched = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
     opt = HipAdam(m.parameters(), lr=1e-4)
     scaler = HipGradScaler()
@@ -58,7 +60,7 @@ def run(B, size, steps):
         ev[3].record()
         torch.cuda.synchronize()
         fw += ev[0].elapsed_time(ev[1]); bw += ev[1].elapsed_time(ev[2]); op += ev[2].elapsed_time(ev[3])
-    print(json.dumps({"batch": B, "size": size, "steps": steps, "ms_per_step_fused": fused_ms,
+    print(json.dumps({"batch": B, "size": size, "steps": steps, "latency_mode": bool(latency), "ms_per_step_fused": fused_ms,
                       "images_per_sec": B / (fused_ms * 1e-3), "forward_ms": fw / steps, "backward_ms": bw / steps,
                       "optimizer_ms": op / steps, "last_loss": loss, "dtype": "f32"}), flush=True)
 
@@ -68,9 +70,10 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--latency", action="store_true", help="latency-mode tile choices (set_latency_mode) for small batches")
     a = ap.parse_args()
     if a.batch:
-        run(a.batch, a.size, a.steps)
+        run(a.batch, a.size, a.steps, a.latency)
     else:
-        run(2, 128, a.steps)        # the reference's batch (train_diffusion.py:59)
-        run(32, 64, a.steps)
+        run(2, 128, a.steps, a.latency)        # the reference's batch (train_diffusion.py:59)
+        run(32, 64, a.steps, a.latency)
