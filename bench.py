@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive generate_seeds leg")
+    ap.add_argument("--e2e-steps", type=int, default=0,
+                    help="steps of the host-inclusive leg (default: max(--steps, 256), independent of a short --steps: with "
+                         "20 steps the leg measures its fixed costs, not the rate)")
     args = ap.parse_args()
 
     from synt_isic_amd import dist as sdist
@@ -193,25 +196,28 @@ def main():
     log(f"timed {K} steps: {ms_per_step:.3f} ms/step -> {value:.3f} images/sec")
 
     # ---- host-inclusive leg (every rank at once, so that at N > 1 the ranks' CPU noise producers compete for the host
-    # as they would in a real sharded run): seeds in -> uint8 images on the host out, K steps of a K-step grid
-    # (identical kernels per step; K = 1000 is the real T=1000 run), extrapolated to 1000 steps like `value`.
+    # as they would in a real sharded run): seeds in -> uint8 images on the host out, KE steps of a KE-step grid
+    # (identical kernels per step; KE = 1000 is the real T=1000 run), extrapolated to 1000 steps like `value`.  KE has its
+    # own floor of 256 steps: the call's fixed costs (first noise segments, pinned ring, download) are ~0.1 s, which a
+    # 20-step run would report as a 2x slower rate.
     e2e = None
+    KE = min(T_FULL, args.e2e_steps if args.e2e_steps > 0 else max(K, 256))
     if not args.no_e2e:
         from synt_isic_amd.dist import shard_range
         lo, hi = shard_range(B * world, world, rank)
         seeds = list(range(lo, hi))
-        sampler.generate_seeds("NV", seeds, T=min(K, 4), size=(SIZE, SIZE))     # sizes the pinned/device noise ring
+        sampler.generate_seeds("NV", seeds, T=min(KE, 4), size=(SIZE, SIZE))     # sizes the pinned/device noise ring
         barrier()
         t0 = time.perf_counter()
-        r = sampler.generate_seeds("NV", seeds, T=K, size=(SIZE, SIZE))
+        r = sampler.generate_seeds("NV", seeds, T=KE, size=(SIZE, SIZE))
         host_images = r.images.cpu().numpy()
         e2e_s = time.perf_counter() - t0
         barrier()
         e2e_s = sdist.max_over_ranks(e2e_s, dev)
-        assert host_images.shape == (B, SIZE, SIZE, 3) and r.steps_done == K
-        e2e = {"images_per_sec": B * world / (e2e_s * T_FULL / K), "seconds": e2e_s, "T": K,
+        assert host_images.shape == (B, SIZE, SIZE, 3) and r.steps_done == KE
+        e2e = {"images_per_sec": B * world / (e2e_s * T_FULL / KE), "seconds": e2e_s, "T": KE,
                "what": "Sampler.generate_seeds on every rank concurrently: per-image CPU torch.Generator noise (x_T + z_t, "
-                       "NoiseStream worker threads), pinned uploads, K steps, uint8 epilogue, download to numpy; no gather"}
+                       "NoiseStream worker threads), pinned uploads, T steps, uint8 epilogue, download to numpy; no gather"}
         log(f"host-inclusive generate_seeds: {e2e['images_per_sec']:.3f} images/sec")
 
     roofline = None
@@ -243,7 +249,7 @@ def main():
         # the committed counter passes of this same command (tools/prof_pmc.sh + tools/make_pmc_summary.py); the newest
         # round's summary that exists is used and named in traffic_source.
         traffic, traffic_src, traffic_class = None, None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
             try:
                 with open(path) as f:
@@ -266,7 +272,8 @@ def main():
         try:
             import csv
             import re
-            path = os.path.join(ROOT, "profiles", "r02", "bench_steps20_kernel_stats.csv")
+            rp_rnd = "r03" if os.path.exists(os.path.join(ROOT, "profiles", "r03", "bench_steps20_kernel_stats.csv")) else "r02"
+            path = os.path.join(ROOT, "profiles", rp_rnd, "bench_steps20_kernel_stats.csv")
             tot_ns, calls = 0.0, 0
             with open(path) as f:
                 for row in csv.DictReader(f):
@@ -275,7 +282,7 @@ def main():
                         calls += int(row["Calls"])
             if calls:
                 rp_us = tot_ns / calls / 1e3
-                rp_src = "profiles/r02/bench_steps20_kernel_stats.csv (committed `rocprofv3 --kernel-trace --stats` of `bench.py --steps 20 --warmup 5`; not measured in this run)"
+                rp_src = f"profiles/{rp_rnd}/bench_steps20_kernel_stats.csv (committed `rocprofv3 --kernel-trace --stats` of `bench.py --steps 20 --warmup 5`; not measured in this run)"
         except (OSError, KeyError, ValueError):
             pass
         roofline = {

@@ -148,8 +148,9 @@ int sisic_denorm_u8(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int 
 /* The reference's three spellings of the same conversion, each in its own fp32 operation order:
  *   form 0  image_generator.py:441-447       trunc(clamp((x+1)/2, 0, 1) * 255)            (= sisic_denorm_u8)
  *   form 1  generate_test.py:94-97           trunc((clamp(x,-1,1) + 1) * 0.5 * 255)       (bit-equal to form 0)
- *   form 2  diffusion_generator.py:231-232   trunc(clip((x+1) * 127.5, 0, 255))           (differs from form 0 where
- *           the single multiplication rounds across an integer boundary)                                     */
+ *   form 2  diffusion_generator.py:231-232   trunc(clip((x+1) * 127.5, 0, 255))           (bit-equal to form 0 as well:
+ *           halving is exact in binary floating point, so (x+1)/2*255 and (x+1)*127.5 round the same real number once;
+ *           tests/test_gpu_kernels.py::test_denorm_u8_three_reference_forms_bit_exact asserts it on every boundary)    */
 int sisic_denorm_u8_form(sisic_ctx*, const float* x, uint8_t* out, int B, int C, int H, int W, int form, void* stream);
 
 /* ---- UNet2DModel ---------------------------------------------------------------- */
@@ -185,6 +186,9 @@ int sisic_unet_set_latency_mode(sisic_unet*, int on);
  * mode 1 on, 0 off, -1 (default) on exactly when latency mode is on.  Same kernels, same arithmetic, same bits; the
  * loop then runs on a library-owned copy of x (written back at the end) so that every address in the graph is stable.   */
 int sisic_unet_set_graph_mode(sisic_unet*, int mode);
+/* How many times this handle has captured + instantiated the sampling step (a second sisic_sample at the same shape,
+ * stream and mode replays the cached graph: the count does not move).                                                  */
+int64_t sisic_unet_graph_builds(const sisic_unet*);
 /* eps = model(sample, timestep).sample.  timesteps: host int64 [B] (one per sample). */
 int sisic_unet_forward(sisic_unet*, const float* sample, const int64_t* timesteps,
                        float* out, int B, int H, int W, void* stream);
@@ -314,8 +318,9 @@ int sisic_mask_patches(sisic_ctx*, const float* image, const uint8_t* masks, flo
  * accumulated per class; reading synchronises the stream.                           */
 int sisic_profile_enable(sisic_ctx*, int on);
 /* kind: 0 = conv3x3, 1 = conv1x1, 2 = groupnorm stats, 3 = attention, 4 = ddpm step,
- *       5 = other, 6 = the dominant kernel alone (conv_winograd_kernel<1,8,8,*,16,false>, a subset of kind 0).  Returns accumulated milliseconds, launches, algorithmic bytes, algorithmic flops (2*MAC of the
- *       direct form) and the flops actually issued to the matrix pipe (fewer for Winograd launches).  */
+ *       5 = other, 6 = the dominant kernel family alone (the stride-1 Winograd launches of conv_winograd_wide_kernel,
+ *       tile_cfg 68 / 69: a subset of kind 0).  Returns accumulated milliseconds, launches, algorithmic bytes, algorithmic
+ *       flops (2*MAC of the direct form) and the flops actually issued to the matrix pipe (fewer for Winograd launches). */
 int sisic_profile_read(sisic_ctx*, int kind, double* ms, int64_t* launches, double* bytes, double* flops,
                        double* flops_executed);
 int sisic_profile_reset(sisic_ctx*);

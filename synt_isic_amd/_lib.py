@@ -84,6 +84,7 @@ SIGNATURES = {
     "sisic_unet_load": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_int64_p]),
     "sisic_unet_set_latency_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "sisic_unet_set_graph_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "sisic_unet_graph_builds": (C.c_int64, [C.c_void_p]),
     "sisic_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, c_int64_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p]),
     "sisic_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int64_p, c_float_p,

@@ -760,6 +760,7 @@ int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* p
 int64_t winograd_packed_numel(int Cout, int Cin) { return winograd_first_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin); }
 
 #include "conv_winograd_wide.inc"
+#include "conv_winograd_col.inc"
 
 // K-split reduction: out = sum_k part[k] + bias + per-sample channel bias + residual (+ReLU), and the GroupNorm partials
 // of the result.  One wave per (image, channel) plane of HW <= 256 pixels; the plane is the only statistics slot.
@@ -905,6 +906,8 @@ static int launch_wino_pro(sisic_ctx* ctx, WinoParams& p, hipStream_t s) {
 //          68 / 69: second geometry, 32 tiles per workgroup, filters straight from global memory into registers:
 //              68 = 128 output channels x 16 waves (Cout > 64), 69 = 64 channels x 8 waves, two workgroups per CU
 //          78 / 79: 68 / 69 in latency mode: input channels K-split so that one image fills the chip (wino_latency_ksplit)
+//          (68 / 69 / 78 / 79 / 91 run the THIRD form, conv_winograd_col.inc -- same tiles, same bits, a wave owns a column of
+//           the position grid -- unless SISIC_WINO_COL=0;  70 / 71 force the third form, 72 / 73 the second: A/B and tests)
 //          90: tiling 67 with the input channels split over four workgroups per tile + splitk_reduce_kernel -- for the
 //              8x8 level, where 64 tiles x 64 channels per workgroup leave 3/4 of the CUs without work
 //          91: the same split on the second geometry: 128 channels x (two images x 16 tiles) per workgroup; bit-identical to 90
@@ -924,13 +927,19 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
                   "conv2d(winograd): per-thread load offsets are 32-bit; this tensor needs the direct kernel");
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
-    if (cfg == 68 || cfg == 69 || cfg == 78 || cfg == 79) {           // second geometry (conv_winograd_wide.inc)
+    static const bool col_default = [] { const char* e = std::getenv("SISIC_WINO_COL"); return !e || std::atoi(e) != 0; }();
+    if ((cfg >= 68 && cfg <= 73) || cfg == 78 || cfg == 79) {           // second / third geometry (conv_winograd_wide.inc, _col.inc)
         SISIC_REQUIRE(!p.ups, "conv2d(winograd wide): no upsample form");
         p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1);
         p.cout_pad = round_up(a.Cout, 128);
-        const bool wide = cfg == 68 || cfg == 78;
-        const int K = cfg >= 78 ? wino_latency_ksplit(a.Cout, a.c0 + a.c1, p.Hc, p.Wc) : 1;
-        if (K == 1) return wide ? launch_wide_pro<128, 16>(ctx, p, s) : launch_wide_pro<64, 8>(ctx, p, s);
+        const bool wide = cfg == 68 || cfg == 78 || cfg == 70 || cfg == 72;
+        const bool col = (cfg == 70 || cfg == 71) ? true : ((cfg == 72 || cfg == 73) ? false : col_default);
+        const int K = (cfg == 78 || cfg == 79) ? wino_latency_ksplit(a.Cout, a.c0 + a.c1, p.Hc, p.Wc) : 1;
+        auto launch = [&]() -> int {
+            if (col) return wide ? launch_col_pro<128, 16>(ctx, p, s) : launch_col_pro<64, 8>(ctx, p, s);
+            return wide ? launch_wide_pro<128, 16>(ctx, p, s) : launch_wide_pro<64, 8>(ctx, p, s);
+        };
+        if (K == 1) return launch();
         // latency mode: the input channels split K ways over workgroups, partial slabs summed by the plane reduction
         const size_t HW = (size_t)p.Hc * p.Wc, planes = (size_t)a.B * a.Cout;
         const size_t need = (size_t)K * planes * HW;
@@ -950,7 +959,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         }
         p.ksplit = K;
         p.part = scratch;
-        SISIC_TRY(wide ? (launch_wide_pro<128, 16>(ctx, p, s)) : (launch_wide_pro<64, 8>(ctx, p, s)));
+        SISIC_TRY(launch());
         const int segs = wino_latency_segments(p.Hc, p.Wc);
         hipLaunchKernelGGL(splitk_reduce_plane_kernel, dim3((unsigned)(planes * segs)), dim3(256), 0, s, scratch, K, (int)planes,
                            (int)HW, segs, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu, a.out, a.stats_out);
@@ -983,7 +992,8 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
             SISIC_REQUIRE(!p.ups && p.Hc <= 8 && p.Wc <= 8, "conv2d(winograd wide, image pairs): plain stride-1 convolutions of at most 8x8 pixels");
             p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1);
             p.cout_pad = round_up(a.Cout, 128);
-            SISIC_TRY((launch_wide_pro<128, 16, true>(ctx, p, s)));
+            if (col_default) SISIC_TRY((launch_col_pro<128, 16, true>(ctx, p, s)));
+            else SISIC_TRY((launch_wide_pro<128, 16, true>(ctx, p, s)));
         } else {
             SISIC_TRY((launch_wino_pro<4, 4, 4, 16>(ctx, p, s)));
         }

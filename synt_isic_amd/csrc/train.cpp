@@ -130,20 +130,7 @@ int prepare_backward_weights(sisic_unet* u, hipStream_t s) {
     return SISIC_OK;
 }
 
-void release_tape(sisic_unet* u) {
-    TrainState* tr = u->train.get();
-    if (!tr) return;
-    for (auto& b : tr->bufs) {
-        if (b->p) unet_pool_put(u, b->p);
-        if (b->stats) unet_pool_put(u, b->stats);
-    }
-    for (float* p : tr->grads_of_bufs) unet_pool_put(u, p);
-    tr->bufs.clear();
-    tr->grads_of_bufs.clear();
-    tr->buf_grad.clear();
-    tr->tape.clear();
-    tr->has_tape = false;
-}
+void release_tape(sisic_unet* u) { unet_release_tape(u); }
 
 struct Bwd {
     sisic_unet* u;
@@ -406,7 +393,7 @@ int sisic_unet_train_forward(sisic_unet* u, const float* sample, const int64_t* 
     SISIC_TRY(unet_grow(&tr->h1, &tr->h1_cap, (size_t)B * Hd));
     SISIC_TRY(unet_grow(&tr->t2, &tr->t2_cap, (size_t)B * Hd));
     SISIC_TRY(unet_grow(&tr->dtproj, &tr->dtproj_cap, (size_t)B * u->tproj_R));
-    SISIC_TRY(unet_grow(&tr->small, &tr->small_cap, (size_t)B * 8192));
+    SISIC_TRY(unet_grow(&tr->small, &tr->small_cap, train_small_floats(u, B)));
     std::vector<float> tv(B);
     for (int b = 0; b < B; ++b) tv[b] = (float)timesteps[b];
     SISIC_TRY(unet_stage_upload(u, tv.data(), (size_t)B, u->t_vals, s));
@@ -501,7 +488,7 @@ int sisic_unet_train_step(sisic_unet* u, const float* images, const float* noise
     float* dpred = pred + n;
     // coefficient rows: host -> device through the pinned ring (2B floats)
     SISIC_TRY(unet_ensure_rows(u, (size_t)B, (size_t)B));
-    SISIC_TRY(unet_grow(&tr->small, &tr->small_cap, (size_t)B * 8192));
+    SISIC_TRY(unet_grow(&tr->small, &tr->small_cap, train_small_floats(u, B)));
     std::vector<float> coef(2 * (size_t)B);
     std::memcpy(coef.data(), sqrt_alpha_prod, B * sizeof(float));
     std::memcpy(coef.data() + B, sqrt_one_minus_alpha_prod, B * sizeof(float));

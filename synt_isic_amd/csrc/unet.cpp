@@ -226,14 +226,37 @@ void reset_derived(sisic_unet* u) {
 }
 
 // ------------------------------------------------------------------ workspace
+void pool_put(sisic_unet* u, float* p);
+
 void loop_graph_drop(sisic_unet* u) {
     if (u->loop_exec) (void)hipGraphExecDestroy(u->loop_exec);
     if (u->loop_graph) (void)hipGraphDestroy(u->loop_graph);
     u->loop_exec = nullptr; u->loop_graph = nullptr; u->loop_valid = false;
 }
 
+// A recorded training forward (the tape) owns pool blocks.  Whatever frees the pool, or lets a captured step write into
+// blocks the tape took from the free list after the capture, makes the tape unusable: forget it, so that
+// sisic_unet_backward answers SISIC_ESTATE instead of reading freed or overwritten activations.
+void tape_drop(sisic_unet* u, bool return_blocks) {
+    TrainState* tr = u->train.get();
+    if (!tr) return;
+    if (return_blocks) {
+        for (auto& b : tr->bufs) {
+            if (b->p) pool_put(u, b->p);
+            if (b->stats) pool_put(u, b->stats);
+        }
+        for (float* p : tr->grads_of_bufs) pool_put(u, p);
+    }
+    tr->bufs.clear();
+    tr->grads_of_bufs.clear();
+    tr->buf_grad.clear();
+    tr->tape.clear();
+    tr->has_tape = false;
+}
+
 void pool_release_all(sisic_unet* u) {
     loop_graph_drop(u);                 // a captured step holds addresses of pool blocks
+    tape_drop(u, false);                // ... and so does a recorded training forward
     for (auto& b : u->pool) (void)hipFree(b.p);
     u->pool.clear();
 }
@@ -585,6 +608,7 @@ int run_forward(sisic_unet* u, const float* sample, const float* tproj, int tpro
 
 namespace sisic {
 int unet_pool_get(sisic_unet* u, size_t floats, float** out) { return pool_get(u, floats, out); }
+void unet_release_tape(sisic_unet* u) { tape_drop(u, true); }
 void unet_pool_put(sisic_unet* u, float* p) { pool_put(u, p); }
 int unet_grow(float** p, size_t* have, size_t want) { return grow(p, have, want); }
 int unet_check_shape(sisic_unet* u, int B, int H, int W) { return check_shape(u, B, H, W); }
@@ -655,6 +679,8 @@ int sisic_unet_set_graph_mode(sisic_unet* u, int mode) {
     return SISIC_OK;
 }
 
+int64_t sisic_unet_graph_builds(const sisic_unet* u) { return u ? u->loop_builds : 0; }
+
 int64_t sisic_unet_workspace_bytes(const sisic_unet* u) {
     int64_t n = 0;
     if (u) for (const auto& b : u->pool) n += (int64_t)b.bytes;
@@ -691,7 +717,10 @@ int sisic_unet_load(sisic_unet* u, int n, const char* const* names, const float*
         seen[idx] = 1;
         SISIC_HIP(hipMemcpy(u->raw + u->offsets[idx], host_ptrs[i], (size_t)numels[i] * sizeof(float), hipMemcpyHostToDevice));
     }
-    // (re)build derived buffers
+    // (re)build derived buffers.  A captured sampling step holds the addresses of the packed filters freed below: drop it
+    // (a replay after load_state_dict would read freed memory).
+    SISIC_HIP(hipDeviceSynchronize());
+    loop_graph_drop(u);
     for (auto p : u->owned) (void)hipFree(p);
     u->owned.clear();
     reset_derived(u);
@@ -739,6 +768,9 @@ static int sample_graph(sisic_unet* u, float* x, int B, int H, int W, int T, con
     const int C = u->cfg.in_channels;
     const size_t n = (size_t)B * C * H * W;
     SISIC_REQUIRE(T <= 1000, "sample: at most 1000 steps per call");
+    // the replayed launches write into the pool blocks they were captured with; a tape recorded since then may own some of
+    // them: the tape does not survive a graph-replayed run (sisic_unet_backward then answers SISIC_ESTATE)
+    tape_drop(u, true);
     hipStream_t s = caller;
     if (!s) {                              // the legacy default stream cannot be captured: a blocking stream of our own,
         if (!u->loop_stream) SISIC_HIP(hipStreamCreate(&u->loop_stream));     // implicitly ordered with the default stream
@@ -806,6 +838,7 @@ static int sample_graph(sisic_unet* u, float* x, int B, int H, int W, int T, con
             u->loop_key.latency = u->latency_mode; u->loop_key.gen = gen;
             for (int k = 0; k < 5; ++k) u->loop_key.ptrs[k] = ptrs[k];
             u->loop_valid = true;
+            u->loop_builds += 1;
         }
         for (; i < T; ++i) {
             if (cancelled(i)) { rc = SISIC_ECANCEL; break; }

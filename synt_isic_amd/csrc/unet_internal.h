@@ -198,6 +198,7 @@ struct sisic_unet {
         const void* ptrs[5] = {};        // tproj, eps_buf, x_work, loop_tables, tproj_cur at capture time: each can be re-allocated
     } loop_key;
     bool loop_valid = false;
+    int64_t loop_builds = 0;             // captures + instantiations so far (sisic_unet_graph_builds)
     hipStream_t loop_stream = nullptr;   // used when the caller's stream is the legacy default stream (not capturable)
     float* x_work = nullptr;             // the loop's own latent buffer: every address inside the graph is library-owned
     size_t x_work_cap = 0;
@@ -221,6 +222,12 @@ namespace sisic {
 // unet.cpp internals used by train.cpp
 int unet_pool_get(sisic_unet* u, size_t floats, float** out);
 void unet_pool_put(sisic_unet* u, float* p);
+// hand the recorded training forward's blocks back to the pool and forget it (backward then answers SISIC_ESTATE)
+void unet_release_tape(sisic_unet* u);
+// floats of TrainState::small: [B, Cout <= 3 max_c] plane sums, then [2][B][Cin <= max_c] GroupNorm sums or [3C] column sums
+inline size_t train_small_floats(const sisic_unet* u, int B) {
+    return (size_t)B * 5 * (size_t)u->max_c + 3 * (size_t)u->max_c + 2 * (size_t)B;
+}
 int unet_grow(float** p, size_t* have, size_t want);
 int unet_check_shape(sisic_unet* u, int B, int H, int W);
 int unet_ensure_rows(sisic_unet* u, size_t t_rows, size_t gn_rows);

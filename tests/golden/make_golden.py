@@ -17,6 +17,13 @@ drift (torch version, refactors) and give the GPU tests a CPU-independent target
                             0, 99, 499, 899, 999 + the final uint8 image (error accumulation over T=1000)
   unet_forward_b1_128.npz   one UNet forward at 3x128x128 (BASELINE config 4's resolution: attention
                             over 1024 and 256 tokens)
+  sample_T1000_seed0_64.npz   (--long) the full 1000-step chain at BASELINE config 2's own resolution: B=1,
+                            3x64x64, seed 0 (image_generator.py:395-403 loop), x after steps 0, 99, 499, 899, 999
+                            + the final uint8 image
+  sample_T1000_seed5_128.npz  (--long) the same at config 4's resolution, 3x128x128, seed 5
+
+``--long`` writes ONLY the two full-length chains (minutes of CPU time each); without it only the
+short fixtures are (re)written.
 """
 import json
 import os
@@ -34,9 +41,22 @@ from synt_isic_amd.weights import DEFAULT_WEIGHT_SEED, state_dict_sha256, synthe
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+def long_chains(sd):
+    """Full T=1000 chains at the headline resolutions (error accumulation at 64x64 and 128x128)."""
+    keep = (0, 99, 499, 899, 999)
+    for name, seed, size in (("sample_T1000_seed0_64.npz", 0, (64, 64)), ("sample_T1000_seed5_128.npz", 5, (128, 128))):
+        img, x0, traj = sampler.sample(sd, [seed], 1000, size, return_trajectory=True, keep_steps=keep)
+        np.savez_compressed(os.path.join(OUT, name), steps=np.array(keep), traj=torch.stack(traj).numpy(), image=img,
+                            final=x0.numpy(), seed=np.array(seed))
+        print(name, os.path.getsize(os.path.join(OUT, name)), flush=True)
+
+
 def main():
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     sd = synthetic_unet_state_dict(DEFAULT_WEIGHT_SEED)
+    if "--long" in sys.argv[1:]:
+        long_chains(sd)
+        return
 
     cos = ddpm.DDPMSchedulerOracle(beta_schedule="squaredcos_cap_v2")
     lin = ddpm.DDPMSchedulerOracle(beta_schedule="linear")

@@ -177,8 +177,9 @@ def test_bench_line_contract():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert 0.3 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
-    assert rf["launches_per_step"] == 31.0 and rf["traffic"] is not None and "traffic_source" in rf
-    # HIP-event brackets against the committed rocprofv3 kernel durations of the same command: within 10 % (other box, gaps)
-    assert rf["rocprofv3_avg_launch_us"] and abs(rf["avg_launch_us"] / rf["rocprofv3_avg_launch_us"] - 1.0) < 0.10
-    assert d["e2e_images_per_sec"] > 0.0        # (over 6 steps the host-inclusive leg is mostly its fixed costs)
+    assert rf["launches_per_step"] == 31.0 and "traffic" in rf and "traffic_source" in rf
+    # (`traffic` and `rocprofv3_avg_launch_us` come from committed profiler files of another run and are labelled so in the
+    #  line; comparing a live timing with them belongs to the measurement script, not to a correctness test -- ADVICE r02)
+    # the host-inclusive leg has its own step count (>= 256) so that its fixed costs do not pose as the rate
+    assert d["e2e"]["T"] >= 256 and d["e2e_images_per_sec"] > 0.5 * d["value"]
 

@@ -181,6 +181,10 @@ def _run_wino(x, w, cfg, **kw):
                                        (69, 2, 16, 16), (69, 2, 64, 64), (69, 1, 32, 48), (69, 3, 18, 10), (69, 2, 9, 23),
                                        # latency mode: the same geometry with the input channels K-split over workgroups
                                        (78, 2, 16, 16), (78, 1, 32, 48), (78, 2, 9, 23), (79, 2, 16, 16), (79, 1, 64, 64),
+                                       # (68 / 69 / 78 / 79 run the third form, conv_winograd_col.inc, since round 3;
+                                       #  72 / 73 force the second form, 70 / 71 the third)
+                                       (72, 2, 16, 16), (72, 3, 18, 10), (73, 2, 64, 64), (73, 2, 9, 23),
+                                       (70, 2, 64, 64), (70, 3, 18, 10), (71, 1, 32, 48), (71, 2, 9, 23),
                                        ])
 def test_conv3x3_winograd(cfg, B, H, W):
     """Winograd F(2x2,3x3) on the MFMA pipe == the float64 convolution, plain and with every fused feature
@@ -300,12 +304,24 @@ def test_conv3x3_winograd_reference_layers_and_identity():
         ww = _rand(cout, cin, 3, 3, seed=140 + i, scale=(cin * 9) ** -0.5)
         bb = _rand(cout, seed=150 + i, scale=0.1)
         outs = {}
-        for cfg in (60, 62, 66, 68, 69):
+        for cfg in (60, 62, 66, 70, 71, 72, 73):
             outs[cfg] = _run_wino(xx, ww, cfg, bias=bb)
             _close(outs[cfg], _conv_ref(xx, ww, bb), what=f"winograd{cfg} layer {cin}->{cout}@{r}")
-        # the second geometry (filters from global memory into registers, 32 tiles per workgroup) performs the same fp32
-        # operations in the same order as the first: identical bits
-        assert torch.equal(outs[68], outs[66]) and torch.equal(outs[69], outs[66])
+        # the second geometry (filters from global memory into registers, 32 tiles per workgroup; 72 / 73) and the third
+        # (a wave owns a column of the position grid, half of the output transform on the accumulators; 70 / 71) perform
+        # the same fp32 operations in the same order as the first: identical bits
+        for cfg in (70, 71, 72, 73):
+            assert torch.equal(outs[cfg], outs[66]), cfg
+        # ... and with every fused feature (prologue, concat seam, embedding, residual, ReLU), ragged planes included
+        B2, H2, W2 = 2, r, max(8, r - 6)
+        x1, x2 = _rand(B2, cin, H2, W2, seed=160 + i), _rand(B2, 24, H2, W2, seed=170 + i)
+        w2 = _rand(cout, cin + 24, 3, 3, seed=180 + i, scale=(cin * 9) ** -0.5)
+        gn = (1.0 + 0.3 * _rand(B2, cin + 24, seed=181 + i), 0.3 * _rand(B2, cin + 24, seed=182 + i))
+        kw = dict(bias=bb, x2=x2, gn=gn, gn_silu=True, chan_bias=_rand(B2, cout, seed=183 + i),
+                  residual=_rand(B2, cout, H2, W2, seed=184 + i), relu=bool(i & 1))
+        fused = {cfg: _run_wino(x1, w2, cfg, **kw) for cfg in (66, 70, 71, 72, 73)}
+        for cfg in (70, 71, 72, 73):
+            assert torch.equal(fused[cfg], fused[66]), ("fused", cfg)
     from synt_isic_amd import ops
     from synt_isic_amd._lib import SisicError
     with pytest.raises(SisicError, match="w_winograd"):
@@ -419,7 +435,8 @@ def test_groupnorm_large_mean_is_stable():
                                            (64, 2, 16, 16, True), (61, 5, 8, 8, False), (67, 3, 6, 10, False),
                                            (0, 2, 64, 64, False), (68, 3, 32, 32, False), (68, 2, 18, 10, False),
                                            (69, 2, 9, 23, False), (69, 2, 32, 48, False), (78, 2, 16, 16, False),
-                                           (79, 2, 18, 10, False)])
+                                           (79, 2, 18, 10, False), (72, 3, 32, 32, False), (73, 2, 9, 23, False),
+                                           (70, 2, 18, 10, False), (71, 2, 32, 48, False)])
 def test_conv_epilogue_groupnorm_partials(cfg, B, H, W, ups):
     """sisic_conv_args.stats_out: the Winograd output transform leaves (count, sum, centred M2) per image, channel and
     workgroup tile; sisic_groupnorm_finalize on them == sisic_groupnorm_stats on the stored tensor."""

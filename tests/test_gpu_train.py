@@ -2,8 +2,10 @@
 
 Parity: every backward kernel against torch.autograd over a float64 evaluation of the same op (per-kernel bound
 1e-5 * max(1,|ref|)); the whole step at B=2, 3x64x64 against torch.autograd over the CPU oracle (oracle/train.py): every
-one of the 330 parameter gradients within 1e-4 * max(1, |ref|_inf), and the weights after one Adam step within fp32
-rounding of torch.optim.Adam's.  Bit-exact: add_noise, run-to-run determinism (no atomics in the backward pass).
+one of the 330 parameter gradients within 1e-4 of THAT TENSOR's own largest reference gradient (measured on MI355X:
+worst 1.5e-5, median 6e-6 -- profiles/r02/test_errors.txt; the fp32 CPU oracle itself sits 5e-6 from its float64
+evaluation), median over the tensors <= 5e-5, and the weights after one Adam step within fp32 rounding of
+torch.optim.Adam's.  Bit-exact: add_noise, run-to-run determinism (no atomics in the backward pass).
 """
 import os
 
@@ -16,6 +18,29 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
 KTOL = 1e-5
+GRAD_REL_WORST = 1e-4        # per parameter tensor: max|g - ref| / max|ref|   (measured 1.5e-5)
+GRAD_REL_MEDIAN = 5e-5       # median of that over the 324 tensors with a non-zero gradient (measured 6e-6)
+PRED_TOL = 5e-5              # the training-mode forward against the oracle's prediction (stated 2e-4; measured ~4e-6)
+
+
+def _grad_errors(grads, ref_grads, label):
+    """(worst, median) of the per-tensor relative gradient error.  to_k.bias has an identically zero gradient (softmax is
+    invariant to a shift of the keys' scores): tensors whose reference gradient is below 1e-8 must be below 1e-8 too and are
+    left out of the relative measure."""
+    rel = []
+    for n, r in ref_grads.items():
+        scale = r.abs().max().item()
+        err = (grads[n] - r).abs().max().item()
+        if scale <= 1e-8:
+            assert err <= 1e-7, f"{label}: gradient of {n} should vanish, got {err:.3e}"
+            continue
+        rel.append((err / scale, n))
+    rel.sort()
+    worst, median = rel[-1], rel[len(rel) // 2]
+    if os.environ.get("SISIC_TEST_ERRLOG"):
+        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
+            f.write(f"{median[0]:.3e}\t{worst[0]:.3e}\trelative gradient error {label}: median / max over {len(rel)} tensors (worst: {worst[1]})\n")
+    return worst, median
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -160,7 +185,7 @@ def test_unet_gradients_match_autograd_over_the_oracle(synthetic_sd, batch, refe
     model.train()
     noisy = scheduler.add_noise(images, noise, timesteps)
     noise_pred = model(noisy, timesteps).sample
-    assert (noise_pred.cpu() - ref_pred).abs().max().item() <= 2e-4
+    assert (noise_pred.cpu() - ref_pred).abs().max().item() <= PRED_TOL
     model.eval()
     assert torch.equal(model(noisy, timesteps).sample, noise_pred)        # the tape-recording forward IS the forward
     model.train()
@@ -171,24 +196,9 @@ def test_unet_gradients_match_autograd_over_the_oracle(synthetic_sd, batch, refe
     assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
     grads = model.grads()
     assert list(grads) == list(ref_grads) and len(grads) == 330
-    worst = ("", 0.0)
-    for name, ref in ref_grads.items():
-        err = (grads[name] - ref).abs().max().item() / max(1.0, ref.abs().max().item())
-        if os.environ.get("SISIC_TEST_ERRLOG"):
-            with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
-                f.write(f"{err:.3e}\t1.0e-04\tgrad {name} (|ref|max {ref.abs().max().item():.3e})\n")
-        if err > worst[1]:
-            worst = (name, err)
-    assert worst[1] <= 1e-4, f"gradient of {worst[0]}: {worst[1]:.3e} of max(1,|ref|)"
-    # the gradients are not just small: relative to each tensor's own scale they agree too (median over tensors)
-    # (to_k.bias has an identically zero gradient -- softmax is invariant to a shift of the keys' scores -- so tensors whose
-    # reference gradient is below 1e-8 are left out of the relative measure)
-    rel = sorted((grads[n] - r).abs().max().item() / r.abs().max().item() for n, r in ref_grads.items()
-                 if r.abs().max().item() > 1e-8)
-    if os.environ.get("SISIC_TEST_ERRLOG"):
-        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
-            f.write(f"{rel[len(rel) // 2]:.3e}\t{rel[-1]:.3e}\trelative gradient error: median / max over {len(rel)} tensors\n")
-    assert rel[len(rel) // 2] <= 1e-3 and rel[-1] <= 5e-2, (rel[len(rel) // 2], rel[-1])
+    worst, median = _grad_errors(grads, ref_grads, "B2 64x64")
+    assert worst[0] <= GRAD_REL_WORST, f"gradient of {worst[1]}: {worst[0]:.3e} of its own largest entry"
+    assert median[0] <= GRAD_REL_MEDIAN, median
     # bit-reproducible: a second forward/backward of the same batch gives the same gradients
     noise_pred2 = model(noisy, timesteps).sample
     mse_loss(noise_pred2, noise).backward()
@@ -208,17 +218,14 @@ def test_unet_gradients_in_latency_mode(synthetic_sd, batch, reference):
     optimizer = HipAdam(model.parameters(), lr=1e-4)
     model.train()
     noise_pred = model(scheduler.add_noise(images, noise, timesteps), timesteps).sample
-    assert (noise_pred.cpu() - ref_pred).abs().max().item() <= 2e-4
+    assert (noise_pred.cpu() - ref_pred).abs().max().item() <= PRED_TOL
     loss = mse_loss(noise_pred, noise)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
     grads = model.grads()
-    worst = max((grads[n] - r).abs().max().item() / max(1.0, r.abs().max().item()) for n, r in ref_grads.items())
-    assert worst <= 1e-4, worst
-    rel = sorted((grads[n] - r).abs().max().item() / r.abs().max().item() for n, r in ref_grads.items()
-                 if r.abs().max().item() > 1e-8)
-    assert rel[len(rel) // 2] <= 1e-3 and rel[-1] <= 5e-2, (rel[len(rel) // 2], rel[-1])
+    worst, median = _grad_errors(grads, ref_grads, "B2 64x64 latency mode")
+    assert worst[0] <= GRAD_REL_WORST and median[0] <= GRAD_REL_MEDIAN, (worst, median)
 
 
 def test_unet_gradients_at_a_ragged_resolution(synthetic_sd):
@@ -241,13 +248,8 @@ def test_unet_gradients_at_a_ragged_resolution(synthetic_sd):
     loss.backward()
     assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
     grads = model.grads()
-    worst_abs = max((grads[n] - r).abs().max().item() / max(1.0, r.abs().max().item()) for n, r in ref_grads.items())
-    rel = sorted((grads[n] - r).abs().max().item() / r.abs().max().item() for n, r in ref_grads.items()
-                 if r.abs().max().item() > 1e-8)
-    if os.environ.get("SISIC_TEST_ERRLOG"):
-        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
-            f.write(f"{rel[len(rel) // 2]:.3e}\t{rel[-1]:.3e}\trelative gradient error at 3x40x56: median / max over {len(rel)} tensors\n")
-    assert worst_abs <= 1e-4 and rel[len(rel) // 2] <= 1e-3 and rel[-1] <= 5e-2, (worst_abs, rel[len(rel) // 2], rel[-1])
+    worst, median = _grad_errors(grads, ref_grads, "B3 40x56")
+    assert worst[0] <= GRAD_REL_WORST and median[0] <= GRAD_REL_MEDIAN, (worst, median)
 
 
 def test_one_adam_step_matches_torch_adam(synthetic_sd, batch, reference):
@@ -352,3 +354,50 @@ def test_training_loop_overfits_one_batch_and_fused_step_agrees(synthetic_sd, tm
         mse_loss(m(x, t).sample, target).backward()
         grads.append(m.grads())
     assert all(torch.equal(grads[0][k], grads[1][k]) for k in grads[0])
+
+
+def test_a_shape_change_or_a_graph_replayed_run_invalidates_the_tape(synthetic_sd, batch):
+    """the recorded forward owns blocks of the activation pool.  An inference call at another shape frees the
+    pool, and a graph-replayed sampling run writes into the blocks it was captured with -- in both cases loss.backward()
+    must answer SISIC_ESTATE instead of reading freed / overwritten activations; a fresh forward then works again."""
+    from synt_isic_amd import _lib
+    from synt_isic_amd.sampler import Sampler
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    from synt_isic_amd.train import HipAdam, mse_loss
+    images, noise, timesteps = (t.to(DEV) for t in batch)
+    model = _new_model(synthetic_sd)
+    scheduler = HipDDPMScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2")
+    HipAdam(model.parameters(), lr=1e-4)
+    noisy = scheduler.add_noise(images, noise, timesteps)
+
+    def fresh_grads():
+        model.train()
+        loss = mse_loss(model(noisy, timesteps).sample, noise)
+        loss.backward()
+        return model.grads()
+
+    ref = fresh_grads()
+    # (1) inference at another resolution between forward and backward: the pool is released
+    model.train()
+    loss = mse_loss(model(noisy, timesteps).sample, noise)
+    model.eval()
+    model(torch.zeros(1, 3, 32, 32, device=DEV), 5)
+    with pytest.raises(_lib.SisicError) as e:
+        loss.backward()
+    assert e.value.code == _lib.SISIC_ESTATE
+    again = fresh_grads()
+    assert all(torch.equal(again[k], ref[k]) for k in ref)
+    # (2) a graph-replayed sampling run at the SAME shape between forward and backward
+    s = Sampler(DEV)
+    s.models["NV"] = model.eval()
+    model.set_graph_mode(1)
+    s.generate_seeds("NV", [1, 2], 6, (64, 64))              # captures the step at B=2, 64x64
+    model.train()
+    loss = mse_loss(model(noisy, timesteps).sample, noise)
+    model.eval()
+    s.generate_seeds("NV", [1, 2], 6, (64, 64))              # replays it
+    with pytest.raises(_lib.SisicError) as e:
+        loss.backward()
+    assert e.value.code == _lib.SISIC_ESTATE
+    again = fresh_grads()
+    assert all(torch.equal(again[k], ref[k]) for k in ref)
