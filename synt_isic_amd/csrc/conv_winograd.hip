@@ -30,12 +30,13 @@
 #ifndef WINO_TIMING
 #define WINO_TIMING 0
 #endif
+#define WINO_STAMP_SLOTS 10      // uint64 per workgroup: 8 phase stamps + HW_ID + XCC_ID (third form)
 #if WINO_TIMING
 #define WINO_STAMP(slot)                                                                                   \
     do {                                                                                                   \
         unsigned long long t_;                                                                             \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                         \
-        if (tid == 0) reinterpret_cast<unsigned long long*>(p.stats)[(size_t)blockIdx.x * 8 + (slot)] = t_; \
+        if (tid == 0) reinterpret_cast<unsigned long long*>(p.stats)[(size_t)blockIdx.x * WINO_STAMP_SLOTS + (slot)] = t_; \
     } while (0)
 #else
 #define WINO_STAMP(slot) do { } while (0)

@@ -111,7 +111,7 @@ def main():
             def run():
                 return ops.conv2d(x, wp, cout, k, bias=bias, x2=x2, stride=stride, upsample=bool(ups),
                                   gn_scale=gs, gn_shift=gb, gn_silu=bool(gn), residual=r, tile_cfg=cfg,
-                                  w_winograd=wino if (cfg == 0 or 60 <= cfg <= 69 or cfg in (78, 79, 90, 91)) else None)
+                                  w_winograd=wino if (cfg == 0 or 60 <= cfg <= 73 or cfg in (78, 79, 90, 91)) else None)
             try:
                 run()
             except Exception as e:  # cfg not applicable
@@ -135,7 +135,7 @@ def main():
         total_flops += count * flops
         if args.cfgs != "auto":
             print(f"{'':34s}    best cfg {best[0]} {best[1]:.1f} us (auto {auto_us:.1f})")
-    print(f"sum over one forward (auto cfg): {total_ms:.3f} ms, {total_flops / total_ms / 1e9:.1f} TFLOP/s")
+    print(f"sum over one forward (auto cfg): {total_ms:.3f} ms, {total_flops / max(total_ms, 1e-9) / 1e9:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":

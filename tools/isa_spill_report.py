@@ -23,34 +23,36 @@ def kernels(path):
             name, body = m.group(1), []
         elif name:
             body.append(line.rstrip("\n"))
-            if line.strip().startswith(".end_amdhsa_kernel"):
-                yield name, body
-                name, body = None, []
     if name:
         yield name, body
 
 
 def report(name, body):
     out = []
-    blocks = []          # (label, loop header or None, depth, lines)
-    cur = ("entry", None, 0, [])
+    blocks = []          # [label, loop header or None, depth, instructions]
+    cur = ["entry", None, 0, []]
+
+    def annotate(text):
+        m = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", text)
+        if m and not cur[3]:
+            cur[1], cur[2] = m.group(1), int(m.group(2))
+        m = re.search(r"Loop Header: Depth=(\d+)", text)
+        if m and not cur[3]:
+            cur[1], cur[2] = cur[0].lstrip(".").lstrip("L"), int(m.group(1))
+
     for ln in body:
-        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", ln)
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", ln) or re.match(r"^; (%bb\.\d+):(.*)$", ln)
         if m:
             blocks.append(cur)
-            cur = (m.group(1), None, 0, [])
+            cur = [m.group(1), None, 0, []]
+            annotate(m.group(2))
             continue
-        m = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", ln)
-        if m and not cur[3]:
-            cur = (cur[0], m.group(1), int(m.group(2)), cur[3])
+        st = ln.strip()
+        if st.startswith(";"):
+            annotate(st)
             continue
-        m = re.search(r"Loop Header: Depth=(\d+)", ln)
-        if m and not cur[3]:
-            cur = (cur[0], cur[0].lstrip("."), int(m.group(1)), cur[3])
-            continue
-        s = ln.strip()
-        if s and not s.startswith(";") and not s.startswith("."):
-            cur[3].append(s)
+        if st and not st.startswith("."):
+            cur[3].append(st)
     blocks.append(cur)
     meta = {}
     for ln in body:

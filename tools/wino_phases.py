@@ -41,18 +41,18 @@ def run(cin, cout, hw, B=64, gn=True, res=True, clock_ghz=2.4, cfg=66):
     if res:
         a.residual = r.data_ptr()
     a.tile_cfg = cfg
-    if cfg == 68:
+    if cfg in (68, 70, 72):
         nwg = B * ((hw + 7) // 8) * ((hw + 15) // 16) * ((cout + 127) // 128)
-    elif cfg == 69:
+    elif cfg in (69, 71, 73):
         nwg = B * ((hw + 7) // 8) * ((hw + 15) // 16) * ((cout + 63) // 64)
     else:
         nwg = B * ((hw + 15) // 16) ** 2 * ((cout + 63) // 64)
-    stamps = torch.zeros(nwg * 8 + 64, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(nwg * 10 + 64, dtype=torch.int64, device=dev)
     a.stats_out = stamps.data_ptr()
     for _ in range(3):
         check(lib.sisic_conv2d(ops.context(dev), C.byref(a), None))
     torch.cuda.synchronize()
-    t = stamps[: nwg * 8].view(nwg, 8).cpu().double()
+    t = stamps[: nwg * 10].view(nwg, 10)[:, :8].cpu().double()
     d = (t[:, 1:] - t[:, :-1]) / (clock_ghz * 1e3)
     life = (t[:, 7] - t[:, 0]) / (clock_ghz * 1e3)
     print(f"--- cfg {cfg}: {cin}->{cout} @{hw}x{hw} B={B} ({nwg} workgroups, {cin // 8} chunks), median us per workgroup "
