@@ -21,6 +21,7 @@
 // Algorithmic bytes per launch: 4*B*(Cin*Hin*Win + Cout*Hout*Wout)
 //   + 4*(Cin*Cout*k*k + Cout) (+ 4*B*Cout*Hout*Wout when a residual is read).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "pack_device.h"
@@ -222,7 +223,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
         }
     };
 
-    auto store_chunk = [&](int buf) {
+    // (buf is a compile-time constant in the channel loop below: no buffer-parity arithmetic in the operand addresses)
+    auto store_chunk = [&](const int buf) {
         float* dst = in_lds + buf * G::IN_BUF + sci * G::CHS + sl;
         const unsigned m = cval ? vmask : 0u;       // padding / missing channels stay zero AFTER the prologue
         float v[G::EPT];
@@ -256,7 +258,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
                 make_float4(rw[4 * i + 0], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]);
     };
 
-    auto compute_chunk = [&](int buf) {
+    auto compute_chunk = [&](const int buf) {
         const float* A = w_lds + buf * G::W_BUF + a_base;
         const float* Bm = in_lds + buf * G::IN_BUF + b_base;
 #pragma unroll
@@ -286,13 +288,21 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const int buf = chunk & 1;
+    auto step = [&](const int chunk, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
         const bool more = chunk + 1 < p.nchunks;
         if (more) load_chunk(chunk + 1);
-        compute_chunk(buf);
-        if (more) store_chunk(buf ^ 1);
+        compute_chunk(BUF);
+        if (more) store_chunk(BUF ^ 1);
         __syncthreads();
+    };
+    {
+        int chunk = 0;
+        for (; chunk + 1 < p.nchunks; chunk += 2) {
+            step(chunk, std::integral_constant<int, 0>{});
+            step(chunk + 1, std::integral_constant<int, 1>{});
+        }
+        if (chunk < p.nchunks) step(chunk, std::integral_constant<int, 0>{});
     }
 
     // ---- K-split: the wave groups hold partial sums over disjoint channel pairs of the same output tile; groups

@@ -80,13 +80,25 @@ class NoiseStream:
         self.B = len(seeds)
         self.device = device
         self.seg = max(1, int(segment_steps))
-        if workers is None:
-            try:
-                cpus = len(os.sched_getaffinity(0))
-            except AttributeError:                      # pragma: no cover
-                cpus = os.cpu_count() or 1
-            workers = max(1, min(self.B, cpus, 16))
-        self.pool = ThreadPoolExecutor(max_workers=workers)
+        # a caller that samples repeatedly (Sampler) keeps the worker pool, the copy stream and the staging buffers in
+        # ``buffer_cache`` between calls: creating them costs milliseconds, a one-image T=50 run is ~110 ms
+        self._own_pool = True
+        if buffer_cache is not None and workers is None and "pool" in buffer_cache:
+            self.pool = buffer_cache["pool"]
+            self._own_pool = False
+        else:
+            if workers is None:
+                try:
+                    cpus = len(os.sched_getaffinity(0))
+                except AttributeError:                      # pragma: no cover
+                    cpus = os.cpu_count() or 1
+                n_workers = max(1, min(cpus, 16))
+            else:
+                n_workers = max(1, int(workers))
+            self.pool = ThreadPoolExecutor(max_workers=n_workers)
+            if buffer_cache is not None and workers is None:
+                buffer_cache["pool"] = self.pool
+                self._own_pool = False
         self.gens = []
         for sd in seeds:
             g = torch.Generator(device="cpu")
@@ -98,15 +110,21 @@ class NoiseStream:
         # pinning ~100 MB costs tens of milliseconds: a caller that samples repeatedly (Sampler) passes a dict in which
         # the two pinned and two device buffers of a shape are kept between calls
         key = (shape, str(device))
-        if buffer_cache is not None and key in buffer_cache:
-            self.host, self.dev = buffer_cache[key]
+        if buffer_cache is not None and buffer_cache.get("shape") == key:
+            self.host, self.dev = buffer_cache["buffers"]
         else:
             self.host = [torch.empty(shape, dtype=torch.float32, pin_memory=True) for _ in range(2)]
             self.dev = [torch.empty(shape, dtype=torch.float32, device=device) for _ in range(2)]
+            if buffer_cache is not None:                # one shape at a time: bounded memory
+                buffer_cache["shape"], buffer_cache["buffers"] = key, (self.host, self.dev)
+        if buffer_cache is not None and buffer_cache.get("copy_stream_device") == str(device):
+            self.copy_stream = buffer_cache["copy_stream"]
+        else:
+            self.copy_stream = torch.cuda.Stream(device)
             if buffer_cache is not None:
-                buffer_cache.clear()                    # one shape at a time: bounded memory
-                buffer_cache[key] = (self.host, self.dev)
-        self.copy_stream = torch.cuda.Stream(device)
+                buffer_cache["copy_stream"], buffer_cache["copy_stream_device"] = self.copy_stream, str(device)
+        # uploads of less than 8 MB per segment (a few images) go on the sampling stream itself
+        self.same_stream = (os.environ.get("SISIC_NOISE_SAME_STREAM", "1") != "0") and self.seg * self.B * int(np.prod(self.chw)) * 4 <= (8 << 20)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]      # upload of slot i finished
         self.uploaded = [False, False]
         self.consumed = [None, None]                               # event after the sampler's last read of slot i
@@ -134,6 +152,12 @@ class NoiseStream:
         for f in self.pending[slot]:
             f.result()
         cur = torch.cuda.current_stream(self.device)
+        if self.same_stream:
+            # small runs (one image): the upload rides the sampling stream itself -- stream order replaces the two events
+            self.dev[slot][:n].copy_(self.host[slot][:n], non_blocking=True)
+            self.ready[slot].record(cur)
+            self.uploaded[slot] = True
+            return self.dev[slot][:n]
         with torch.cuda.stream(self.copy_stream):
             if self.consumed[slot] is not None:
                 self.copy_stream.wait_event(self.consumed[slot])
@@ -150,7 +174,15 @@ class NoiseStream:
         self.consumed[slot] = ev
 
     def close(self) -> None:
-        self.pool.shutdown(wait=True)
+        if self._own_pool:
+            self.pool.shutdown(wait=True)
+        else:                                            # a shared pool: wait for this run's draws only
+            for tasks in self.pending:
+                for f in tasks or []:
+                    f.result()
+            for slot in range(2):                        # ... and for the uploads out of the shared pinned buffers
+                if self.uploaded[slot]:
+                    self.ready[slot].synchronize()
 
 
 @dataclass
@@ -208,11 +240,14 @@ def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: t
 
 def segment_bounds(T: int, seg: int, per_step: int) -> List[int]:
     """Step boundaries of the segments a streamed run is cut into (``NoiseStream``): ``seg`` steps each, except that a run
-    whose segment is a noticeable amount of RNG (more than 8 M normals: 64 images at 64x64 draw 50 M per 64 steps) starts
-    with 4, 8, 16, ... steps, so that the GPU starts after a few milliseconds instead of a whole segment's worth.  The
-    draws do not depend on the segmentation.  For one 128x128 image the three extra ``sisic_sample`` calls of a T=50 run
-    cost 70 ms against 12 ms of RNG saved (measured), hence the threshold."""
-    bounds, n = [0], (4 if per_step * seg > 8_000_000 else seg)
+    whose segment is a noticeable amount of RNG (more than 1 M normals: one 128x128 image draws 3 M per 64 steps, 64 images
+    at 64x64 draw 50 M) starts with 4, 8, 16, ... steps, so that the GPU starts after a millisecond or two instead of a
+    whole segment's worth.  The draws do not depend on the segmentation.  (Round 2 kept one 128x128 image in ONE segment
+    because every extra ``sisic_sample`` call cost ~20 ms: a segment of another length re-allocated the per-step tables,
+    which rebuilt the captured graph, and every call ran its first step eagerly.  The tables now have a fixed size and a
+    call that finds its graph replays from step 0, so an extra segment costs its launches only.)"""
+    ramp_min = int(os.environ.get("SISIC_NOISE_RAMP_MIN", "1000000"))
+    bounds, n = [0], (4 if per_step * seg > ramp_min else seg)
     while bounds[-1] < T:
         bounds.append(min(T, bounds[-1] + min(n, seg)))
         n *= 2

@@ -279,9 +279,10 @@ def test_color_postprocessing_matches_oracle_bit_exact(tmp_path):
     assert s.load_color_statistics(str(tmp_path / "color_statistics.json")) == 2 and "NV" in s.color_statistics
 
 
-def test_streamed_segments_cover_the_run_and_ramp_only_for_big_batches():
-    """sampler.segment_bounds: contiguous segments over [0, T], none longer than the stream's buffers; a batch whose segment
-    is a lot of RNG starts with 4, 8, 16, ... steps, a single image does not."""
+def test_streamed_segments_cover_the_run_and_ramp_when_a_segment_is_a_lot_of_rng():
+    """sampler.segment_bounds: contiguous segments over [0, T], none longer than the stream's buffers; a run whose segment
+    is more than a million normals (one 128x128 image: 3 M per 64 steps) starts with 4, 8, 16, ... steps, one 64x64 image
+    (0.8 M) does not."""
     from synt_isic_amd.sampler import segment_bounds
     for T in (1, 3, 4, 50, 64, 65, 130, 1000):
         for seg in (1, 8, 64):
@@ -289,6 +290,7 @@ def test_streamed_segments_cover_the_run_and_ramp_only_for_big_batches():
                 b = segment_bounds(T, seg, per)
                 assert b[0] == 0 and b[-1] == T and all(0 < y - x <= seg for x, y in zip(b[:-1], b[1:]))
     assert segment_bounds(1000, 64, 64 * 3 * 64 * 64)[:6] == [0, 4, 12, 28, 60, 124]
-    assert segment_bounds(50, 64, 3 * 128 * 128) == [0, 50]
-    assert segment_bounds(130, 64, 3 * 128 * 128) == [0, 64, 128, 130]
+    assert segment_bounds(50, 64, 3 * 128 * 128) == [0, 4, 12, 28, 50]
+    assert segment_bounds(50, 64, 3 * 64 * 64) == [0, 50]
+    assert segment_bounds(130, 64, 3 * 64 * 64) == [0, 64, 128, 130]
 
