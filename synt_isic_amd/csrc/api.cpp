@@ -109,7 +109,8 @@ int sisic_destroy(sisic_ctx* ctx) {
 
 int64_t sisic_conv_packed_numel(int Cout, int Cin, int ksize) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3 && ksize != 7)) return -1;
-    return (int64_t)conv_cin_pad(Cin, ksize) * ksize * ksize * conv_cout_pad(Cout);
+    // (1x1: the generic layout followed by conv_pointwise.hip's A-fragment layout, the same number of elements)
+    return (int64_t)conv_cin_pad(Cin, ksize) * ksize * ksize * conv_cout_pad(Cout) * (ksize == 1 ? 2 : 1);
 }
 
 int sisic_conv_pack_weights(sisic_ctx* ctx, const float* w, int Cout, int Cin, int ksize, float* packed, void* stream) {

@@ -140,6 +140,10 @@ int launch_add_relu(sisic_ctx*, const float* y, const float* identity, float* ou
 int launch_gradcam(sisic_ctx*, const float* y, const float* outp, const float* fc_w, const float* bias, float* cam, int B, int C,
                    int h, int w, int S, int target, hipStream_t s);
 int conv_stats_slots(const sisic_conv_args& a);
+// conv_pointwise.hip: the lean 1x1 kernel (tile_cfg 20)
+bool conv_pointwise_applicable(const sisic_conv_args& a);
+int conv_pointwise_stats_slots(const sisic_conv_args& a);
+int launch_conv_pointwise(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
 // mean_rstd (optional, training): [B, groups, 2] = (mean, rstd) of every (sample, group)
 int launch_gn_finalize(sisic_ctx*, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
                        int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,

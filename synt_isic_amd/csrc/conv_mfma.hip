@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
 // OIHW -> [Cin_pad][KK][cout_pad], zero padded
 __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, int cin_pad, int cout_pad,
                                  float* __restrict__ out) {
-    const size_t total = (size_t)cin_pad * KK * cout_pad;
+    const size_t total = (size_t)cin_pad * KK * cout_pad * (KK == 1 ? 2 : 1);      // 1x1: both layouts (pack_device.h)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         conv_pack_elem(i, w, Cout, Cin, KK, cin_pad, cout_pad, out);
     }
@@ -467,7 +467,7 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
     SISIC_REQUIRE(k == 1 || k == 3 || k == 7, "conv_pack: ksize %d unsupported", k);
     const int cin_pad = conv_cin_pad(Cin, k), cout_pad = conv_cout_pad(Cout);
     const size_t total = (size_t)cin_pad * k * k * cout_pad;
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    const int blocks = (int)std::min<size_t>((total * (k == 1 ? 2 : 1) + 255) / 256, 4096);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, k * k, cin_pad, cout_pad, packed);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
@@ -606,6 +606,13 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         // 1x1: the image is a flat row of H*W pixels
         p.Hin = 1; p.Win = a.Hin * a.Win; p.Hc = 1; p.Wc = p.Win; p.Hout = 1; p.Wout = p.Win; p.ups = 0;
         SISIC_REQUIRE(!a.upsample, "conv2d: 1x1 with upsample");
+        // tile_cfg 20: the lean pointwise kernel (conv_pointwise.hip) for the shapes it takes -- whole 128-pixel tiles and
+        // 32-channel chunks -- unless SISIC_POINTWISE=0; the generic tilings below for everything else
+        static const bool pw_on = [] { const char* e = std::getenv("SISIC_POINTWISE"); return !e || std::atoi(e) != 0; }();
+        if ((cfg == 0 && pw_on && conv_pointwise_applicable(a)) || cfg == 20) {
+            if (slots_query) { *slots_query = conv_pointwise_stats_slots(a); return SISIC_OK; }
+            return launch_conv_pointwise(ctx, a, s);
+        }
         if (cfg == 0) cfg = (p.Wout <= 64) ? 22 : (p.Wout <= 256 ? 25 : 24);   // measured (tools/conv_bench.py, B=64)
         switch (cfg) {
             case 21: return launch_cfg<1, 1, 2, 2, 1, 4, 256, 16>(ctx, p, s);

@@ -154,14 +154,19 @@ __device__ __forceinline__ double wave64_sum_f64(double v) {
 //     M2 = sum_i M2_i + sum_i n_i (mean_i - mean)^2
 // is evaluated in float64 with fixed-order butterflies, so the result is independent of timing and as robust against
 // |mean| >> std as the shifted single pass of gn_stats_kernel.
-__global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restrict__ st0, int c0, int slots0,
+// (four (image, group) pairs per workgroup, one per wave: a quarter of the workgroups to dispatch -- the launch is 2048
+//  one-wave jobs of a microsecond each at batch 64, and most of its 5 us was getting them onto the chip)
+constexpr int GNF_WAVES = 4;
+__global__ void __launch_bounds__(64 * GNF_WAVES) gn_finalize_kernel(const float4* __restrict__ st0, int c0, int slots0,
                                                          const float4* __restrict__ st1, int c1, int slots1,
-                                                         int groups, float eps, const float* __restrict__ gamma,
+                                                         int groups, int n_jobs, float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ scale,
                                                          float* __restrict__ shift, float* __restrict__ mean_rstd) {
     const int C = c0 + c1, gs = C / groups;
-    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
-    const int lane = threadIdx.x;
+    const int job = blockIdx.x * GNF_WAVES + (threadIdx.x >> 6);
+    if (job >= n_jobs) return;               // whole waves leave: no barrier below
+    const int b = job / groups, g = job % groups;
+    const int lane = threadIdx.x & 63;
     // the group's channels are one contiguous run of partials in each producer's buffer ([b][c][slot])
     const int ca = g * gs, cb = ca + gs;
     const int a0 = min(ca, c0), b0 = min(cb, c0);                 // channels [a0, b0) of the first producer
@@ -211,8 +216,8 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const float4* __restric
     const float rstd = 1.0f / sqrtf((float)var + eps);
     const float meanf = (float)mean;
     if (mean_rstd && lane == 0) {
-        mean_rstd[2 * (size_t)blockIdx.x] = meanf;
-        mean_rstd[2 * (size_t)blockIdx.x + 1] = rstd;
+        mean_rstd[2 * (size_t)job] = meanf;
+        mean_rstd[2 * (size_t)job + 1] = rstd;
     }
     if (lane < gs) {
         const float sc = my_gamma * rstd;
@@ -237,9 +242,9 @@ int launch_gn_finalize(sisic_ctx* ctx, const float* st0, int c0, int slots0, con
                   "groupnorm_finalize: C=%d groups=%d slots=%d/%d", C, groups, slots0, slots1);
     (void)HW;   // the element count travels with the partials
     ProfileScope prof(ctx, s, PK_GN, 16.0 * B * (c0 * (double)slots0 + c1 * (double)slots1) + 8.0 * B * C, 0.0);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, reinterpret_cast<const float4*>(st0), c0,
-                       slots0, reinterpret_cast<const float4*>(st1), c1, slots1, groups, eps, gamma, beta, scale,
-                       shift, mean_rstd);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(B * groups, GNF_WAVES)), dim3(64 * GNF_WAVES), 0, s,
+                       reinterpret_cast<const float4*>(st0), c0, slots0, reinterpret_cast<const float4*>(st1), c1, slots1, groups,
+                       B * groups, eps, gamma, beta, scale, shift, mean_rstd);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

@@ -6,9 +6,22 @@
 
 namespace sisic {
 
-// OIHW -> [Cin_pad][KK][cout_pad], zero padded (conv_mfma.hip)
+// OIHW -> [Cin_pad][KK][cout_pad], zero padded (conv_mfma.hip).  1x1 filters carry a second layout behind the first (twice
+// the elements): [8-channel chunk][32-channel block][lane = (ci & 1) * 32 + co % 32][(ci % 8) / 2] -- the A fragments of
+// conv_pointwise.hip, one 16-byte load per lane and 8 input channels.
 __device__ __forceinline__ void conv_pack_elem(size_t i, const float* __restrict__ w, int Cout, int Cin, int KK, int cin_pad,
                                                int cout_pad, float* __restrict__ out) {
+    const size_t first = (size_t)cin_pad * KK * cout_pad;
+    if (i >= first) {                   // (KK == 1 only: the callers iterate 2 * first elements then)
+        const size_t j = i - first;
+        const int s = (int)(j & 3), ln = (int)((j >> 2) & 63);
+        const size_t blk = j >> 8;
+        const int n_co32 = cout_pad >> 5;
+        const int mb = (int)(blk % n_co32), chunk = (int)(blk / n_co32);
+        const int co2 = 32 * mb + (ln & 31), ci2 = 8 * chunk + 2 * s + (ln >> 5);
+        out[i] = (co2 < Cout && ci2 < Cin) ? w[(size_t)co2 * Cin + ci2] : 0.0f;
+        return;
+    }
     const int co = (int)(i % cout_pad);
     const size_t r = i / cout_pad;
     const int tap = (int)(r % KK);

@@ -372,6 +372,41 @@ def test_conv1x1(cfg, H, W):
     _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"conv1x1 fused cfg{cfg}")
 
 
+@pytest.mark.parametrize("B,c0,c1,cout,H,W", [(2, 64, 0, 128, 32, 32), (3, 128, 64, 64, 16, 16), (2, 256, 128, 128, 8, 16),
+                                              (2, 256, 0, 768, 16, 16), (1, 32, 32, 70, 16, 24), (2, 96, 0, 200, 16, 8)])
+def test_conv1x1_pointwise(B, c0, c1, cout, H, W):
+    """tile_cfg 20 (conv_pointwise.hip): the lean 1x1 kernel -- filters straight into registers from their second packing,
+    32-channel chunks of the input through LDS -- against the float64 convolution with every fused feature, bit-equal to
+    the generic kernel (same FMA chain in the same channel order), taken by the auto dispatch, and refusing ragged shapes."""
+    from synt_isic_amd import ops
+    x = _rand(B, c0, H, W, seed=400)
+    x2 = _rand(B, c1, H, W, seed=401) if c1 else None
+    w = _rand(cout, c0 + c1, 1, 1, seed=402, scale=(c0 + c1) ** -0.5)
+    b = _rand(cout, seed=403)
+    res = _rand(B, cout, H, W, seed=404)
+    cb = _rand(B, cout, seed=405)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=406), 0.3 * _rand(B, c0 + c1, seed=407))
+    for kw in (dict(bias=b, x2=x2), dict(bias=b, x2=x2, gn=gn, gn_silu=False, residual=res),
+               dict(x2=x2, gn=gn, gn_silu=True, chan_bias=cb, relu=True)):
+        y = _run_conv(x, w, 20, **kw)
+        _close(y, _conv_ref(x, w, **kw), what="pointwise conv1x1")
+        assert torch.equal(y, _run_conv(x, w, 25, **kw)) and torch.equal(y, _run_conv(x, w, 0, **kw))
+    # GroupNorm partials of the result: one slot per 32 pixels
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 1, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=20, with_stats=True)
+    assert st is not None and tuple(st.shape) == (B, cout, H * W // 32, 4)
+    G = 2 if cout % 32 else 32
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=408), 0.1 * _rand(cout, seed=409)
+    sc, sh = ops.groupnorm_finalize(st, H * W, d(gamma), d(beta), G, 1e-5)
+    yc = y.cpu().double()
+    ref = F.group_norm(yc, G, gamma.double(), beta.double(), 1e-5)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=KTOL, what="groupnorm from the pointwise kernel's partials")
+    from synt_isic_amd._lib import SisicError
+    with pytest.raises(SisicError, match="pointwise"):
+        _run_conv(_rand(1, 40, 8, 8, seed=410), _rand(64, 40, 1, 1, seed=411), 20)       # 40 channels, 64 pixels
+
+
 def test_conv_reference_layer_shapes():
     """The distinct (Cin, Cout, resolution) classes of the reference UNet at 64x64, B=1."""
     shapes = [(3, 64, 64), (64, 64, 64), (192, 64, 64), (128, 128, 32), (384, 128, 32), (256, 256, 16),

@@ -40,7 +40,7 @@ LAYERS = [
     ("down 256->256 s2 16->8", 1, 256, 0, 256, 16, 3, 2, 0, 0, 0),
     ("256->256 @8 gn+res", 11, 256, 0, 256, 8, 3, 1, 0, 1, 1),
     ("256+256->256 @8 gn", 3, 256, 256, 256, 8, 3, 1, 0, 1, 0),
-    ("1x1 qkv 256->768 @16 gn", 5, 256, 0, 768, 16, 1, 1, 0, 1, 0),
+    ("1x1 qkv 256->768 @16 gn", 5, 256, 0, 768, 16, 1, 1, 0, 2, 0),
     ("1x1 out 256->256 @16 res", 5, 256, 0, 256, 16, 1, 1, 0, 0, 1),
     ("1x1 sc 256+256->256 @16", 2, 256, 256, 256, 16, 1, 1, 0, 0, 0),
     ("1x1 sc 256+128->128 @32", 1, 256, 128, 128, 32, 1, 1, 0, 0, 0),
@@ -110,7 +110,7 @@ def main():
         for cfg in cfgs_for(k, stride, args.cfgs):
             def run():
                 return ops.conv2d(x, wp, cout, k, bias=bias, x2=x2, stride=stride, upsample=bool(ups),
-                                  gn_scale=gs, gn_shift=gb, gn_silu=bool(gn), residual=r, tile_cfg=cfg,
+                                  gn_scale=gs, gn_shift=gb, gn_silu=(gn == 1), residual=r, tile_cfg=cfg,
                                   w_winograd=wino if (cfg == 0 or 60 <= cfg <= 73 or cfg in (78, 79, 90, 91)) else None)
             try:
                 run()
