@@ -173,20 +173,14 @@ struct Bwd {
             SISIC_TRY(grad(op.residual, &gr));
             SISIC_TRY(launch_add_inplace(u->ctx, gr, dy, (size_t)B * c.cout * Ho * Wo, s));
         }
-        // ---- bias and time-embedding projection: sums of dy over the pixels of each (sample, channel) plane
-        float* S = tr->small;                                  // [B, Cout]
-        SISIC_TRY(launch_plane_sums(u->ctx, dy, B * c.cout, Ho * Wo, S, s));
+        // ---- bias and time-embedding projection: sums of dy over the pixels of each (sample, channel) plane, one launch
         if (op.qkv_of) {
-            float* tmp = tr->small + (size_t)B * c.cout;       // [3C]
-            SISIC_TRY(launch_col_sums(u->ctx, S, B, c.cout, c.cout, tmp, 0, s));
-            const int C = op.qkv_of->c;
-            const int idx[3] = {op.qkv_of->q_b, op.qkv_of->k_b, op.qkv_of->v_b};
-            for (int i = 0; i < 3; ++i)
-                SISIC_HIP(hipMemcpyAsync(grad_of(u, idx[i]), tmp + (size_t)i * C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, s));
+            SISIC_TRY(launch_bias_grad(u->ctx, dy, B, c.cout, Ho * Wo, grad_of(u, op.qkv_of->q_b), grad_of(u, op.qkv_of->k_b),
+                                       grad_of(u, op.qkv_of->v_b), op.qkv_of->c, nullptr, 0, s));
         } else {
-            SISIC_TRY(launch_col_sums(u->ctx, S, B, c.cout, c.cout, grad_of(u, c.b_idx), 0, s));
+            SISIC_TRY(launch_bias_grad(u->ctx, dy, B, c.cout, Ho * Wo, grad_of(u, c.b_idx), nullptr, nullptr, 0,
+                                       op.temb_off >= 0 ? tr->dtproj + op.temb_off : nullptr, u->tproj_R, s));
         }
-        if (op.temb_off >= 0) SISIC_TRY(launch_copy_cols(u->ctx, S, B, c.cout, tr->dtproj + op.temb_off, u->tproj_R, s));
         // ---- weights
         {
             WgradArgs a;
@@ -195,21 +189,13 @@ struct Bwd {
             a.gn_scale = op.gn_scale; a.gn_shift = op.gn_shift; a.gn_silu = op.silu ? 1 : 0;
             a.dy = dy; a.Cout = c.cout;
             const size_t need = conv_wgrad_scratch_floats(a);
-            const size_t wn = (size_t)c.cout * Cin * c.k * c.k;
-            SISIC_TRY(unet_grow(&tr->wgrad_part, &tr->wgrad_part_cap, need + wn));
-            if (op.qkv_of) {
-                float* tmp = tr->wgrad_part + need;            // [3C, C], split into the three projections' gradients
-                a.dw = tmp;
-                SISIC_TRY(launch_conv_wgrad(u->ctx, a, tr->wgrad_part, need, s));
-                const int C = op.qkv_of->c;
-                const int idx[3] = {op.qkv_of->q_w, op.qkv_of->k_w, op.qkv_of->v_w};
-                for (int i = 0; i < 3; ++i)
-                    SISIC_HIP(hipMemcpyAsync(grad_of(u, idx[i]), tmp + (size_t)i * C * C, (size_t)C * C * sizeof(float),
-                                             hipMemcpyDeviceToDevice, s));
+            SISIC_TRY(unet_grow(&tr->wgrad_part, &tr->wgrad_part_cap, need));
+            if (op.qkv_of) {            // [3C, C] leaves the reduction as the three projections' gradients
+                a.dw = grad_of(u, op.qkv_of->q_w); a.dw1 = grad_of(u, op.qkv_of->k_w); a.dw2 = grad_of(u, op.qkv_of->v_w);
             } else {
                 a.dw = grad_of(u, c.w_idx);
-                SISIC_TRY(launch_conv_wgrad(u->ctx, a, tr->wgrad_part, need, s));
             }
+            SISIC_TRY(launch_conv_wgrad(u->ctx, a, tr->wgrad_part, need, s));
         }
         // ---- data
         if (!op.in0) return SISIC_OK;                          // the network input
@@ -218,6 +204,14 @@ struct Bwd {
         const size_t da_n = (size_t)B * Cin * Hc * Wc;
         SISIC_TRY(unet_grow(&tr->scratch, &tr->scratch_cap, da_n));
         float* da = tr->scratch;
+        float* g0 = nullptr;
+        float* g1 = nullptr;
+        SISIC_TRY(grad(op.in0, &g0));
+        if (op.in1) SISIC_TRY(grad(op.in1, &g1));
+        // an input that is neither normalised, nor upsampled, nor a concatenation receives its gradient straight from the
+        // convolution's epilogue: out = conv(dy) + residual with residual = out = the input's gradient buffer (every element is
+        // read and then written by the same thread) -- no scratch tensor, no accumulate launch; g + y in place of g += y: same bits
+        const bool in_place = !op.norm && !op.ups && !op.in1;
         {
             sisic_conv_args a{};
             a.in0 = dy; a.c0 = c.cout; a.B = B; a.Hin = Ho; a.Win = Wo;
@@ -225,16 +219,14 @@ struct Bwd {
             a.w_packed = packed_t; a.Cout = Cin;
             a.w_winograd = (op.stride == 1 && !op.qkv_of && u->use_winograd) ? c.wino_t : nullptr;
             a.out = da;
+            if (in_place) { a.out = g0; a.residual = g0; }
             if (u->latency_mode) {           // the forward's small-batch tile choices (unet.cpp, Fwd::conv) for the data gradient
                 if (c.k == 3 && op.stride == 1 && a.w_winograd && Cin > 4 && Ho >= 12 && Wo >= 12) a.tile_cfg = 79;
                 else if (c.k == 1) a.tile_cfg = 22;
             }
             SISIC_TRY(launch_conv2d(u->ctx, a, s));
         }
-        float* g0 = nullptr;
-        float* g1 = nullptr;
-        SISIC_TRY(grad(op.in0, &g0));
-        if (op.in1) SISIC_TRY(grad(op.in1, &g1));
+        if (in_place) return SISIC_OK;
         if (op.norm) {
             float* sums = tr->small + (size_t)B * c.cout;      // [2][B][Cin]
             SISIC_TRY(launch_gn_bwd(u->ctx, da, op.in0_ptr, op.c0, op.in1_ptr, op.c1, B, op.H * op.W, u->cfg.norm_groups,

@@ -16,6 +16,8 @@ struct WgradArgs {
     const float* dy = nullptr;   // [B, Cout, Hout, Wout]
     int Cout = 0;
     float* dw = nullptr;         // [Cout, c0+c1, k, k] (OIHW, the state-dict layout)
+    float* dw1 = nullptr;        // 1x1 only, with dw2: the gradient leaves as three [Cout/3, Cin] tensors (fused q/k/v projection)
+    float* dw2 = nullptr;
 };
 size_t conv_wgrad_scratch_floats(const WgradArgs& a);
 int launch_conv_wgrad(sisic_ctx*, const WgradArgs& a, float* part, size_t part_floats, hipStream_t s);
@@ -40,6 +42,10 @@ PackJob pack_job_conv(const float* w, int Cout, int Cin, int k, float* packed);
 PackJob pack_job_wino_first(const float* w, int Cout, int Cin, float* packed);
 PackJob pack_job_wino_wide(int Cout, int Cin, float* packed);
 int launch_plane_sums(sisic_ctx*, const float* x, int planes, int HW, float* out, hipStream_t s);
+// bias gradient of a convolution in one launch: db[c] = sum over (b, pixels) of dy; split > 0: channels [0, split) -> db0,
+// [split, 2 split) -> db1, the rest -> db2; tproj (optional): the per-(image, channel) sums into column c of [B, tproj_ld]
+int launch_bias_grad(sisic_ctx*, const float* dy, int B, int C, int HW, float* db0, float* db1, float* db2, int split, float* tproj,
+                     int tproj_ld, hipStream_t s);
 int launch_col_sums(sisic_ctx*, const float* m, int rows, int cols, int ld, float* out, int accumulate, hipStream_t s);
 int launch_copy_cols(sisic_ctx*, const float* src, int rows, int cols, float* dst, int ld_dst, hipStream_t s);
 // sums: scratch [2][B][c0+c1]

@@ -265,8 +265,10 @@ __global__ void __launch_bounds__((WgradGeom<KS, STRIDE, TR, TC>::NTHR), 2) conv
 // of the slabs (in slab order, four loads in flight), the eight partial sums are added in group order: a fixed summation
 // tree, so the result is bit-reproducible.  (One thread per element walking all slabs left a 64x64 weight gradient with
 // 256 slabs at 1 TB/s: 64 us per launch.)
+// (out1 / out2 / split: the fused q/k/v projection's gradient [3C][C] leaves as its three [C][C] tensors -- split = C * C)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, int ksplit, size_t n,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, float* __restrict__ out1 = nullptr,
+                                                           float* __restrict__ out2 = nullptr, size_t split = 0) {
     __shared__ float red[8][32];
     const int seg = threadIdx.x >> 5, j = threadIdx.x & 31;
     const int per = (ksplit + 7) / 8;
@@ -289,7 +291,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
             float t = red[0][j];
 #pragma unroll
             for (int g = 1; g < 8; ++g) t += red[g][j];
-            out[i] = t;
+            if (split == 0 || i < split) out[i] = t;
+            else if (i < 2 * split) out1[i - split] = t;
+            else out2[i - 2 * split] = t;
         }
         __syncthreads();
     }
@@ -377,7 +381,8 @@ int launch_conv_wgrad(sisic_ctx* ctx, const WgradArgs& a, float* part, size_t pa
         }
     }
     const int blocks = (int)std::min<size_t>((n + 31) / 32, 8192);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, p.ksplit, n, a.dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, p.ksplit, n, a.dw, a.dw1, a.dw2,
+                       a.dw1 ? n / 3 : (size_t)0);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
@@ -441,6 +446,47 @@ __global__ void col_sum2_kernel(const float* __restrict__ ma, const float* __res
 
 int launch_col_sums(sisic_ctx*, const float* m, int rows, int cols, int ld, float* out, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(col_sum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, m, rows, cols, ld, out, accumulate);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// Bias gradient of one convolution in ONE launch (was plane_sum_kernel + col_sum_kernel (+ copy_cols_kernel, + three device
+// copies for the fused q/k/v projection): ~200 launches of 5-10 us per training step).  One workgroup per output channel:
+// its sixteen waves sum the channel's B planes (plane b by wave b % 16, lanes striding the pixels, then the wave butterfly --
+// the order of plane_sum_kernel), lane 0 of each wave leaves S[b] in LDS; then S[b] goes to the time-embedding gradient
+// (column tproj_col + c of a [B, tproj_ld] matrix) when the convolution added a projected embedding, and the sum over b in
+// batch order (the order of col_sum_kernel) is the bias gradient.  The fused q/k/v projection writes its three biases.
+// Same sums in the same order as the kernels it replaces: the gradients keep their bits.
+// (sixteen waves per channel: with four, a 64-channel layer at batch 32 was 64 blocks walking 8 planes each -- 47 us)
+__global__ void __launch_bounds__(1024) bias_grad_kernel(const float* __restrict__ dy, int B, int C, int HW, float* __restrict__ db0,
+                                                         float* __restrict__ db1, float* __restrict__ db2, int split,
+                                                         float* __restrict__ tproj, int tproj_ld) {
+    extern __shared__ float S[];          // [B]
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 16) {
+        const float* src = dy + ((size_t)b * C + c) * HW;
+        float s = 0.0f;
+        for (int i = lane; i < HW; i += 64) s += src[i];
+        s = wave_sum_t(s);
+        if (lane == 0) S[b] = s;
+    }
+    __syncthreads();
+    if (tproj)
+        for (int b = threadIdx.x; b < B; b += 1024) tproj[(size_t)b * tproj_ld + c] = S[b];
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int b = 0; b < B; ++b) t += S[b];
+        if (split <= 0) db0[c] = t;
+        else if (c < split) db0[c] = t;
+        else if (c < 2 * split) db1[c - split] = t;
+        else db2[c - 2 * split] = t;
+    }
+}
+
+int launch_bias_grad(sisic_ctx*, const float* dy, int B, int C, int HW, float* db0, float* db1, float* db2, int split, float* tproj,
+                     int tproj_ld, hipStream_t s) {
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(1024), (size_t)B * sizeof(float), s, dy, B, C, HW, db0, db1, db2, split, tproj,
+                       tproj_ld);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
