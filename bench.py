@@ -41,6 +41,9 @@ SIZE = 64
 T_FULL = 1000
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32-in MFMA = vector fp32 peak
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec
+# (the 157.3 is the peak at the 2.4 GHz boost clock; under an f32-MFMA load the chip sustains 2.07-2.10 GHz -- tools/issue_probe.hip,
+#  profiles/r03/issue_probe.txt -- i.e. 136-138 TFLOP/s: roofline.frac stays against 157.3, frac_at_sustained_clock is beside it)
+SUSTAINED_CLOCK_FRACTION = 2.09 / 2.4
 
 
 def _affinity() -> int:
@@ -277,7 +280,7 @@ def main():
             tot_ns, calls = 0.0, 0
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    if re.search(r"conv_winograd_wide_kernel<\d+, \d+, \d, false>|conv_winograd_kernel<1, 8, 8, \d, 16, false>", row["Name"]):
+                    if re.search(r"conv_winograd_(wide|col)_kernel<\d+, \d+, \d, false>|conv_winograd_kernel<1, 8, 8, \d, 16, false>", row["Name"]):
                         tot_ns += float(row["TotalDurationNs"])
                         calls += int(row["Calls"])
             if calls:
@@ -287,13 +290,14 @@ def main():
             pass
         roofline = {
             "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (GroupNorm+SiLU prologue, "
-                      "bias/temb/residual + GroupNorm partials epilogue): conv_winograd_wide_kernel<128,16> (Cout > 64), "
-                      "conv_winograd_wide_kernel<64,8> (Cout <= 64, two workgroups per CU)",
+                      "bias/temb/residual + GroupNorm partials epilogue): conv_winograd_col_kernel<128,16> (Cout > 64), "
+                      "conv_winograd_col_kernel<64,8> (Cout <= 64, two workgroups per CU)",
             "bound": "mfma",
             "achieved": d_exec,
             "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": d_exec / PEAK_FP32_MFMA_TFLOPS,
+            "frac_at_sustained_clock": d_exec / (PEAK_FP32_MFMA_TFLOPS * SUSTAINED_CLOCK_FRACTION),
             "achieved_is": "FLOPs issued to the matrix pipe (16/36 of the direct form's 2*MAC) / HIP-event launch time; "
                            "<= 1 of the f32 MFMA peak by construction",
             "traffic": traffic,

@@ -60,12 +60,12 @@ def main():
         summary[name] = e
         # the dominant kernel family of bench.py's roofline (profile slot "conv3x3_winograd_main"): the stride-1, non-upsampled
         # F(2x2,3x3) launches in their three geometries
-        is_main = (re.search(r"conv_winograd_wide_kernel<\d+, \d+, \d, false>", name) or      # (not the image-pair form of the 8x8 level)
+        is_main = (re.search(r"conv_winograd_(wide|col)_kernel<\d+, \d+, \d, false>", name) or      # (not the image-pair form of the 8x8 level)
                    re.search(r"conv_winograd_kernel<1, 8, 8, \d, 16, false>", name))
         if is_main:
             main_bytes += (rd + wb) * n
             main_calls += n
-        is_conv3 = ("conv_winograd_kernel" in name or "conv_winograd_wide_kernel" in name or re.search(r"conv_mfma_kernel<3,", name) or
+        is_conv3 = ("conv_winograd_kernel" in name or "conv_winograd_wide_kernel" in name or "conv_winograd_col_kernel" in name or re.search(r"conv_mfma_kernel<3,", name) or
                     "conv3x3_smallcout" in name or "splitk_reduce" in name)
         if is_conv3:
             conv_bytes += (rd + wb) * n
@@ -74,8 +74,8 @@ def main():
     summary["_conv3x3_all"] = {"hbm_MB_per_launch": conv_bytes / max(conv_calls, 1) / 1e6, "launches": conv_calls,
                                "note": "HBM bytes of all kernels launched by 3x3 convolutions / sisic_conv2d calls"}
     summary["_winograd_main"] = {"hbm_MB_per_launch": main_bytes / max(main_calls, 1) / 1e6, "launches": main_calls,
-                                 "note": "HBM bytes per launch of the stride-1 F(2x2,3x3) kernels (conv_winograd_wide_kernel<128,16>, <64,8>, "
-                                         "conv_winograd_kernel<1,8,8,*,16,false>) = bench.py roofline.traffic"}
+                                 "note": "HBM bytes per launch of the stride-1 F(2x2,3x3) kernels (conv_winograd_col_kernel<128,16>, <64,8>; "
+                                         "earlier rounds: conv_winograd_wide_kernel, conv_winograd_kernel<1,8,8,*,16,false>) = bench.py roofline.traffic"}
     with open(dst, "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print(json.dumps(summary["_conv3x3_all"]))
