@@ -337,6 +337,9 @@ def test_T1000_chain_at_the_headline_resolutions(sampler, golden_dir, name, size
         assert err <= 1e-2, f"step {step}: {err:.3e}"
     end = float(np.abs(res.latents.cpu().numpy() - g["final"]).max())
     assert end <= 1e-2, end
+    # regression guard far inside the stated tolerance: the chain is contractive (x0 is clipped every step) and the library
+    # measures 1e-5 at both resolutions (profiles/r03/test_errors.txt)
+    assert max(worst, end) <= 5e-4, (worst, end)
     img = res.images.cpu().numpy()
     frac = float(np.mean(np.abs(img.astype(int) - g["image"].astype(int)) <= 1))
     if os.environ.get("SISIC_TEST_ERRLOG"):

@@ -11,7 +11,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
-FWD_TOL = 2e-4
+FWD_TOL = 2e-4          # the stated tolerance
+FWD_GUARD = 4e-5        # regression guard: what the library measures is ~4e-6 (profiles/r03/test_errors.txt); a change that costs an
+                        # order of magnitude of accuracy fails here long before the stated tolerance
+
+
+def _log(err, what):
+    if os.environ.get("SISIC_TEST_ERRLOG"):
+        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
+            f.write(f"{err:.3e}\t{FWD_TOL:.1e}\t{what}\n")
 
 
 @pytest.fixture(scope="module")
@@ -47,17 +55,20 @@ def test_forward_matches_golden_and_oracle(model, golden_dir, synthetic_sd):
     out = model(x.to(DEV), t.to(DEV)).sample                      # per-sample int64[B] timesteps on the GPU
     assert out.shape == (2, 3, 64, 64) and out.device.type == "cuda" and out.dtype == torch.float32
     err = (out.cpu() - torch.from_numpy(g["y"])).abs().max().item()
-    assert err <= FWD_TOL, f"forward vs golden: {err:.3e}"
+    _log(err, "unet forward B2 64x64 vs golden")
+    assert err <= FWD_TOL and err <= FWD_GUARD, f"forward vs golden: {err:.3e}"
     with torch.no_grad():
         ref = ounet.unet_forward(synthetic_sd, x, t)
-    assert (out.cpu() - ref).abs().max().item() <= FWD_TOL
+    assert (out.cpu() - ref).abs().max().item() <= FWD_GUARD
 
 
 def test_forward_128_matches_golden(model, golden_dir):
     """BASELINE config 4's resolution (3x128x128): attention over 1024 and 256 tokens, five 64-row tile rounds."""
     g = np.load(os.path.join(golden_dir, "unet_forward_b1_128.npz"))
     y = model(torch.from_numpy(g["x"]).to(DEV), int(g["t"])).sample.cpu().numpy()
-    assert np.abs(y - g["y"]).max() <= FWD_TOL
+    err = float(np.abs(y - g["y"]).max())
+    _log(err, "unet forward B1 128x128 vs golden")
+    assert err <= FWD_TOL and err <= FWD_GUARD, err
 
 
 def test_timestep_argument_forms(model, synthetic_sd):
