@@ -484,11 +484,11 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
 static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s, int* slots_query);
 
 // Winograd F(2x2,3x3) is taken for 3x3 stride-1 convolutions with transformed filters at hand: when forced by
-// tile_cfg 60..73 / 78 / 79 / 90 / 91, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
+// tile_cfg 60..74 / 78 / 79 / 90 / 91, or automatically from 12x12 outputs up and (K-split form) at 8x8 (per-thread load offsets
 // there are 32-bit).  Returns the tile configuration, 0 = not Winograd.
 static int winograd_cfg(const sisic_conv_args& a) {
     if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4) || a.upsample == 2) return 0;
-    if ((a.tile_cfg >= 60 && a.tile_cfg <= 73) || a.tile_cfg == 78 || a.tile_cfg == 79 || a.tile_cfg == 90 || a.tile_cfg == 91) return a.tile_cfg;
+    if ((a.tile_cfg >= 60 && a.tile_cfg <= 74) || a.tile_cfg == 78 || a.tile_cfg == 79 || a.tile_cfg == 90 || a.tile_cfg == 91) return a.tile_cfg;
     if (a.tile_cfg != 0) return 0;
     const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
     const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
@@ -498,6 +498,13 @@ static int winograd_cfg(const sisic_conv_args& a) {
         static const bool wide_on = [] { const char* e = std::getenv("SISIC_WINO_WIDE"); return !e || std::atoi(e) != 0; }();
         // measured per layer (tools/conv_bench.py, profiles/r02/conv_bench_geometries.txt): the 128-channel form wins 8-12 % on
         // every Cout >= 128 layer, the 64-channel two-workgroups-per-CU form 1-10 % on every Cout <= 64 layer
+        // fp32-equivalent products on the bf16 matrix pipe (conv_winograd_bf3.inc) unless SISIC_WINO_BF16X3=0: 64 channels x
+        // 16 x 16 pixels per workgroup, so only where those tiles are full; measured 1.36 - 1.43x the third f32 form on every
+        // such layer of the headline model (profiles/r03/conv_bench_bf16x3.txt), the same error against float64
+        static const bool bf3_on = [] { const char* e = std::getenv("SISIC_WINO_BF16X3"); return !e || std::atoi(e) != 0; }();
+        if (bf3_on && !a.upsample && a.Cout % 64 == 0 && Hout % 16 == 0 && Wout % 16 == 0 && a.c0 + a.c1 >= 16 &&
+            4.0 * a.Cout * Hout * Wout < 2147483648.0)
+            return 74;
         if (wide_on && !a.upsample) return a.Cout > 64 ? 68 : 69;
         return 66;
     }
@@ -578,7 +585,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     const bool wino_ups9 = use_wino && a.upsample && !a.gn_scale && winograd_cfg(a) == 66;
     ProfileScope prof(slots_query ? nullptr : ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops,
                       use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops,
-                      (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || (winograd_cfg(a) >= 68 && winograd_cfg(a) <= 73) || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
+                      (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || (winograd_cfg(a) >= 68 && winograd_cfg(a) <= 74) || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
 
     if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50 || cfg == 51)) {
         if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)
@@ -590,7 +597,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         SISIC_REQUIRE(!slots_query, "conv2d: internal: slot query on the Winograd path");
         return launch_conv_winograd(ctx, a, a.w_winograd, winograd_cfg(a), s);
     }
-    SISIC_REQUIRE((cfg < 60 || cfg > 73) && cfg != 78 && cfg != 79 && cfg != 90 && cfg != 91, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
+    SISIC_REQUIRE((cfg < 60 || cfg > 74) && cfg != 78 && cfg != 79 && cfg != 90 && cfg != 91, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 2>(ctx, p, s);   // 2-channel chunks: 4 spill 256 B/lane (13 weight float4 + 15 halo elements per thread)

@@ -745,6 +745,7 @@ static int64_t winograd_wide_numel(int Cout, int Cin) { return (int64_t)round_up
 __global__ void winograd_pack_wide_kernel(const float* __restrict__ u_first, int cin_pad, int cout_pad, int cout_pad128,
                                           float* __restrict__ out);
 
+int launch_winograd_pack_bf3(sisic_ctx*, int Cout, int Cin, float* packed, hipStream_t s);
 int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* packed, hipStream_t s) {
     const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout);
     const size_t total = (size_t)cin_pad * cout_pad;
@@ -755,13 +756,28 @@ int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* p
     hipLaunchKernelGGL(winograd_pack_wide_kernel, dim3((unsigned)std::min<size_t>((total_w + 255) / 256, 4096)), dim3(256), 0, s,
                        packed, cin_pad, cout_pad, cout_pad128, packed + winograd_first_numel(Cout, Cin));
     SISIC_HIP(hipGetLastError());
-    return SISIC_OK;
+    return launch_winograd_pack_bf3(nullptr, Cout, Cin, packed, s);
 }
 
-int64_t winograd_packed_numel(int Cout, int Cin) { return winograd_first_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin); }
+// third region: the split filters of the bf16x3 form (conv_winograd_bf3.inc), twice the dwords of the wide layout
+static int64_t winograd_bf3_numel(int Cout, int Cin) { return 2 * winograd_wide_numel(Cout, Cin); }
+int64_t winograd_packed_numel(int Cout, int Cin) {
+    return winograd_first_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin) + winograd_bf3_numel(Cout, Cin);
+}
 
 #include "conv_winograd_wide.inc"
 #include "conv_winograd_col.inc"
+#include "conv_winograd_bf3.inc"
+
+int launch_winograd_pack_bf3(sisic_ctx*, int Cout, int Cin, float* packed, hipStream_t s) {
+    const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout), cout_pad128 = round_up(Cout, 128);
+    const size_t total = (size_t)winograd_bf3_numel(Cout, Cin);
+    unsigned* dst = reinterpret_cast<unsigned*>(packed + winograd_first_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin));
+    hipLaunchKernelGGL(winograd_pack_bf3_kernel, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, packed, cin_pad,
+                       cout_pad, cout_pad128, dst);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
 
 // K-split reduction: out = sum_k part[k] + bias + per-sample channel bias + residual (+ReLU), and the GroupNorm partials
 // of the result.  One wave per (image, channel) plane of HW <= 256 pixels; the plane is the only statistics slot.
@@ -929,6 +945,12 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
     static const bool col_default = [] { const char* e = std::getenv("SISIC_WINO_COL"); return !e || std::atoi(e) != 0; }();
+    if (cfg == 74) {                // fp32-equivalent products on the bf16 pipe (conv_winograd_bf3.inc)
+        SISIC_REQUIRE(!p.ups, "conv2d(winograd bf16x3): no upsample form");
+        p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1);
+        p.cout_pad = round_up(a.Cout, 128);
+        return launch_bf3_pro(ctx, p, s);
+    }
     if ((cfg >= 68 && cfg <= 73) || cfg == 78 || cfg == 79) {           // second / third geometry (conv_winograd_wide.inc, _col.inc)
         SISIC_REQUIRE(!p.ups, "conv2d(winograd wide): no upsample form");
         p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1);

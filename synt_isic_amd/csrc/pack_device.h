@@ -72,6 +72,34 @@ __device__ __forceinline__ void winograd_pack_wide_elem(size_t i, const float* _
     out[o] = co < cout_pad ? u_first[((size_t)ci * 16 + xi) * cout_pad + co] : 0.0f;
 }
 
+// third packing of U = G g G^T: the A operands of the bf16x3 form's MFMAs, [chunk of 8 ci][position][32-channel block][kind][lane][4 dwords].
+// Lane (co = lane & 31, g = lane >> 5) carries input channels 4 g .. 4 g + 3 of the chunk: dwords 0-1 the first term of
+// channels (1 : 0) and (3 : 2) of the group, dwords 2-3 the second term; kind 0: (U_hi, U_mid), kind 1: (U_hi, U_lo)
+__device__ __forceinline__ void winograd_pack_bf3_elem(size_t i, const float* __restrict__ u_first, int cout_pad, int cout_pad128,
+                                                       unsigned* __restrict__ out) {
+    const int n_co32 = cout_pad128 >> 5;
+    const int d = (int)(i & 3), ln = (int)((i >> 2) & 63), kind = (int)((i >> 8) & 1);
+    size_t r = i >> 9;
+    const int blk = (int)(r % n_co32); r /= n_co32;
+    const int pos = (int)(r % 16);
+    const int chunk = (int)(r / 16);
+    const int co = 32 * blk + (ln & 31), g = ln >> 5;
+    const int term = (d >> 1) == 0 ? 0 : (kind == 0 ? 1 : 2);           // 0 hi, 1 mid, 2 lo
+    unsigned pk = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int ci = 8 * chunk + 4 * g + 2 * (d & 1) + e;
+        const float v = co < cout_pad ? u_first[((size_t)ci * 16 + pos) * cout_pad + co] : 0.0f;
+        const unsigned hi = __float_as_uint(v) & 0xffff0000u;
+        const float r1 = v - __uint_as_float(hi);
+        const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(mid);
+        const unsigned t = term == 0 ? hi : (term == 1 ? mid : __float_as_uint(r2));
+        pk |= (t >> 16) << (16 * e);
+    }
+    out[i] = pk;
+}
+
 // W'[ci][co][KK-1-t] = W[co][ci][t]: the filter of the backward-data convolution; i over Cout * Cin * KK
 __device__ __forceinline__ void transpose_flip_elem(size_t i, const float* __restrict__ w, int Cout, int Cin, int KK,
                                                     float* __restrict__ wt) {

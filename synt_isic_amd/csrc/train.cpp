@@ -63,6 +63,7 @@ int build_repack_plan(sisic_unet* u) {
         if (c->wino) {
             ph[0].push_back(pack_job_wino_first(w, c->cout, c->cin, c->wino));
             ph[1].push_back(pack_job_wino_wide(c->cout, c->cin, c->wino));
+            ph[1].push_back(pack_job_wino_bf3(c->cout, c->cin, c->wino));
         }
         if (c == &u->conv_in) continue;                       // the network input needs no gradient
         SISIC_REQUIRE(c->raw_t && c->packed_t, "repack plan: backward filters are not prepared");
@@ -71,6 +72,7 @@ int build_repack_plan(sisic_unet* u) {
         if (c->wino_t) {
             ph[1].push_back(pack_job_wino_first(c->raw_t, c->cin, c->cout, c->wino_t));
             ph[2].push_back(pack_job_wino_wide(c->cin, c->cout, c->wino_t));
+            ph[2].push_back(pack_job_wino_bf3(c->cin, c->cout, c->wino_t));
         }
     }
     for (ResnetW* r : unet_resnets(u)) {

@@ -25,7 +25,7 @@ int launch_transpose_flip(sisic_ctx*, const float* w, int Cout, int Cin, int KK,
 
 // repack.hip: one re-layout of one tensor inside a batched launch (pack_batch_kernel)
 struct PackJob {
-    enum Kind : int { COPY = 0, TRANSPOSE2D, FLIP, CONV_PACK, WINO_FIRST, WINO_WIDE };
+    enum Kind : int { COPY = 0, TRANSPOSE2D, FLIP, CONV_PACK, WINO_FIRST, WINO_WIDE, WINO_BF3 };
     int kind;
     int a, b, c, d, e;          // shape arguments of the kind's per-element function (see the constructors in repack.hip)
     const float* src;
@@ -41,6 +41,7 @@ PackJob pack_job_flip(const float* w, int Cout, int Cin, int KK, float* wt);
 PackJob pack_job_conv(const float* w, int Cout, int Cin, int k, float* packed);
 PackJob pack_job_wino_first(const float* w, int Cout, int Cin, float* packed);
 PackJob pack_job_wino_wide(int Cout, int Cin, float* packed);
+PackJob pack_job_wino_bf3(int Cout, int Cin, float* packed);
 int launch_plane_sums(sisic_ctx*, const float* x, int planes, int HW, float* out, hipStream_t s);
 // bias gradient of a convolution in one launch: db[c] = sum over (b, pixels) of dy; split > 0: channels [0, split) -> db0,
 // [split, 2 split) -> db1, the rest -> db2; tproj (optional): the per-(image, channel) sums into column c of [B, tproj_ld]

@@ -185,6 +185,8 @@ def _run_wino(x, w, cfg, **kw):
                                        #  72 / 73 force the second form, 70 / 71 the third)
                                        (72, 2, 16, 16), (72, 3, 18, 10), (73, 2, 64, 64), (73, 2, 9, 23),
                                        (70, 2, 64, 64), (70, 3, 18, 10), (71, 1, 32, 48), (71, 2, 9, 23),
+                                       # 74: fp32-equivalent (bf16x3, six products) on the bf16 matrix pipe, 64 tiles per workgroup
+                                       (74, 2, 16, 16), (74, 2, 64, 64), (74, 1, 32, 48), (74, 3, 18, 10), (74, 2, 9, 23),
                                        ])
 def test_conv3x3_winograd(cfg, B, H, W):
     """Winograd F(2x2,3x3) on the MFMA pipe == the float64 convolution, plain and with every fused feature
@@ -471,7 +473,8 @@ def test_groupnorm_large_mean_is_stable():
                                            (0, 2, 64, 64, False), (68, 3, 32, 32, False), (68, 2, 18, 10, False),
                                            (69, 2, 9, 23, False), (69, 2, 32, 48, False), (78, 2, 16, 16, False),
                                            (79, 2, 18, 10, False), (72, 3, 32, 32, False), (73, 2, 9, 23, False),
-                                           (70, 2, 18, 10, False), (71, 2, 32, 48, False)])
+                                           (70, 2, 18, 10, False), (71, 2, 32, 48, False), (74, 3, 32, 32, False),
+                                           (74, 2, 18, 10, False)])
 def test_conv_epilogue_groupnorm_partials(cfg, B, H, W, ups):
     """sisic_conv_args.stats_out: the Winograd output transform leaves (count, sum, centred M2) per image, channel and
     workgroup tile; sisic_groupnorm_finalize on them == sisic_groupnorm_stats on the stored tensor."""
