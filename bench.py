@@ -40,6 +40,7 @@ BATCH_PER_GPU = 64
 SIZE = 64
 T_FULL = 1000
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense f32-in MFMA = vector fp32 peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (no sparsity)
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec
 # (the 157.3 is the peak at the 2.4 GHz boost clock; under an f32-MFMA load the chip sustains 2.07-2.10 GHz -- tools/issue_probe.hip,
 #  profiles/r03/issue_probe.txt -- i.e. 136-138 TFLOP/s: roofline.frac stays against 157.3, frac_at_sustained_clock is beside it)
@@ -241,7 +242,9 @@ def main():
         prof = ops.profile_read(dev)
         ops.profile_enable(dev, False)
         c3 = prof["conv3x3"]
-        dom = prof["conv3x3_winograd_main"]
+        # the dominant kernel: the bf16x3 Winograd form (tile_cfg 74) unless it is switched off (SISIC_WINO_BF16X3=0)
+        bf3 = prof["conv3x3_winograd_bf16x3"]["launches"] > 0
+        dom = prof["conv3x3_winograd_bf16x3"] if bf3 else prof["conv3x3_winograd_main"]
         def rates(slot):
             sec = max(slot["ms"], 1e-9) * 1e-3
             return (slot["flops"] / sec / 1e12, slot["flops_executed"] / sec / 1e12, slot["bytes"] / sec / 1e9)
@@ -257,7 +260,11 @@ def main():
             try:
                 with open(path) as f:
                     js = json.load(f)
-                if "_winograd_main" in js:
+                if bf3 and "_winograd_bf16x3" not in js:
+                    continue
+                if bf3:
+                    traffic = js["_winograd_bf16x3"]["hbm_MB_per_launch"] * 1e6
+                elif "_winograd_main" in js:
                     traffic = js["_winograd_main"]["hbm_MB_per_launch"] * 1e6
                 else:
                     e = js["sisic::conv_winograd_kernel<1, 8, 8, 2, 16, false>"]
@@ -280,7 +287,9 @@ def main():
             tot_ns, calls = 0.0, 0
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    if re.search(r"conv_winograd_(wide|col)_kernel<\d+, \d+, \d, false>|conv_winograd_kernel<1, 8, 8, \d, 16, false>", row["Name"]):
+                    pat = (r"conv_winograd_bf3_kernel<\d>" if bf3 else
+                           r"conv_winograd_(wide|col)_kernel<\d+, \d+, \d, false>|conv_winograd_kernel<1, 8, 8, \d, 16, false>")
+                    if re.search(pat, row["Name"]):
                         tot_ns += float(row["TotalDurationNs"])
                         calls += int(row["Calls"])
             if calls:
@@ -288,18 +297,44 @@ def main():
                 rp_src = f"profiles/{rp_rnd}/bench_steps20_kernel_stats.csv (committed `rocprofv3 --kernel-trace --stats` of `bench.py --steps 20 --warmup 5`; not measured in this run)"
         except (OSError, KeyError, ValueError):
             pass
+        if bf3:
+            # six bf16 term products per fp32 product (three MFMAs of two); the bf16 pipe's dense peak from the guide
+            issued = 6.0 * d_exec
+            head = {
+                "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) with fp32-equivalent products on "
+                          "v_mfma_f32_32x32x16_bf16 (every operand split exactly into three bf16 terms, six of the nine term "
+                          "products, fp32 accumulate; GroupNorm+SiLU prologue, bias/temb/residual + GroupNorm partials epilogue): "
+                          "conv_winograd_bf3_kernel<PRO>, 64 channels x 16x16 pixels per workgroup, one per CU",
+                "bound": "mfma",
+                "achieved": d_exec,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": d_exec / PEAK_FP32_MFMA_TFLOPS,
+                "achieved_is": "fp32 multiply-adds x 2 of the Winograd algorithm (16/36 of the direct form's 2*MAC) / HIP-event launch "
+                               "time, against the f32 MFMA peak -- the rate an f32-pipe kernel would need; the kernel itself issues "
+                               "six bf16 products per fp32 product to the bf16 pipe: see bf16_pipe",
+                "bf16_pipe": {"issued_TFLOPs": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": issued / PEAK_BF16_MFMA_TFLOPS,
+                              "what": "6 x the fp32-equivalent rate against the dense bf16 MFMA peak (MI355X_MICROARCH.md)"},
+                "products": "bf16x3: x = hi + mid + lo exactly (8 + 8 + 8 significant bits), hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + "
+                            "lo*hi summed in the MFMA's fp32 accumulator; measured error against float64 equal to the f32-MFMA "
+                            "forms' (tests/test_gpu_kernels.py: 1.5-2.1e-7 relative, bound 1e-5)",
+            }
+        else:
+            head = {
+                "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (GroupNorm+SiLU prologue, "
+                          "bias/temb/residual + GroupNorm partials epilogue): conv_winograd_col_kernel<128,16> (Cout > 64), "
+                          "conv_winograd_col_kernel<64,8> (Cout <= 64, two workgroups per CU)",
+                "bound": "mfma",
+                "achieved": d_exec,
+                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": d_exec / PEAK_FP32_MFMA_TFLOPS,
+                "frac_at_sustained_clock": d_exec / (PEAK_FP32_MFMA_TFLOPS * SUSTAINED_CLOCK_FRACTION),
+                "achieved_is": "FLOPs issued to the matrix pipe (16/36 of the direct form's 2*MAC) / HIP-event launch time; "
+                               "<= 1 of the f32 MFMA peak by construction",
+            }
         roofline = {
-            "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (GroupNorm+SiLU prologue, "
-                      "bias/temb/residual + GroupNorm partials epilogue): conv_winograd_col_kernel<128,16> (Cout > 64), "
-                      "conv_winograd_col_kernel<64,8> (Cout <= 64, two workgroups per CU)",
-            "bound": "mfma",
-            "achieved": d_exec,
-            "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": d_exec / PEAK_FP32_MFMA_TFLOPS,
-            "frac_at_sustained_clock": d_exec / (PEAK_FP32_MFMA_TFLOPS * SUSTAINED_CLOCK_FRACTION),
-            "achieved_is": "FLOPs issued to the matrix pipe (16/36 of the direct form's 2*MAC) / HIP-event launch time; "
-                           "<= 1 of the f32 MFMA peak by construction",
+            **head,
             "traffic": traffic,
             "traffic_source": traffic_src,
             "avg_launch_us": dom["ms"] * 1e3 / n_dom,
@@ -346,6 +381,9 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": "fp32 storage, accumulation and results; the stride-1 conv3x3 kernel forms each fp32 product from six "
+                          "exact bf16 term products on the bf16 MFMA (roofline.products) -- same measured error against float64 "
+                          "as the f32 MFMA kernels it replaces (SISIC_WINO_BF16X3=0 runs those)",
             "data": "synthetic",
             "config": {"workload": f"batch={B} per GPU, 3x{SIZE}x{SIZE}, T={T_FULL} DDPM sampling "
                                    f"(BASELINE configs[1]{'; configs[2] sharding' if world > 1 else ''})",

@@ -318,9 +318,10 @@ int sisic_mask_patches(sisic_ctx*, const float* image, const uint8_t* masks, flo
  * accumulated per class; reading synchronises the stream.                           */
 int sisic_profile_enable(sisic_ctx*, int on);
 /* kind: 0 = conv3x3, 1 = conv1x1, 2 = groupnorm stats, 3 = attention, 4 = ddpm step,
- *       5 = other, 6 = the dominant kernel family alone (the stride-1 Winograd launches of conv_winograd_wide_kernel,
- *       tile_cfg 68 / 69: a subset of kind 0).  Returns accumulated milliseconds, launches, algorithmic bytes, algorithmic
- *       flops (2*MAC of the direct form) and the flops actually issued to the matrix pipe (fewer for Winograd launches). */
+ *       5 = other, 6 = the f32-MFMA Winograd kernels alone (tile_cfg 66 / 68-73 / 78 / 79), 7 = the bf16x3 Winograd kernel
+ *       alone (tile_cfg 74, the dominant kernel; 6 and 7 are subsets of kind 0).  Returns accumulated milliseconds, launches,
+ *       algorithmic bytes, algorithmic flops (2*MAC of the direct form) and the fp32 multiply-adds x 2 of the algorithm that
+ *       ran (16/36 of the direct form for Winograd launches; kind 7 issues six bf16 products for each of them).          */
 int sisic_profile_read(sisic_ctx*, int kind, double* ms, int64_t* launches, double* bytes, double* flops,
                        double* flops_executed);
 int sisic_profile_reset(sisic_ctx*);

@@ -42,9 +42,9 @@ void set_error(const char* fmt, ...);
         if (_rc != SISIC_OK) return _rc; \
     } while (0)
 
-// PK_WINO_MAIN: the dominant kernel on its own -- conv_winograd_kernel<1,8,8,PRO,16,false> launches are credited to
-// PK_CONV3 (the class) AND to this slot (same event pair)
-enum ProfileKind { PK_CONV3 = 0, PK_CONV1 = 1, PK_GN = 2, PK_ATTN = 3, PK_DDPM = 4, PK_OTHER = 5, PK_WINO_MAIN = 6, PK_COUNT = 7 };
+// PK_WINO_MAIN / PK_WINO_BF3: the Winograd kernel families on their own -- the f32-MFMA forms (tile_cfg 66, 68-73, 78, 79) and
+// the bf16x3 form (tile_cfg 74); their launches are credited to PK_CONV3 (the class) AND to their slot (same event pair)
+enum ProfileKind { PK_CONV3 = 0, PK_CONV1 = 1, PK_GN = 2, PK_ATTN = 3, PK_DDPM = 4, PK_OTHER = 5, PK_WINO_MAIN = 6, PK_WINO_BF3 = 7, PK_COUNT = 8 };
 
 struct ProfileSlot {
     double ms = 0, bytes = 0, flops = 0, flops_exec = 0;   // flops: algorithmic (2*MAC of the direct form); flops_exec: issued to the matrix pipe

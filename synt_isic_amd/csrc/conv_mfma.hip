@@ -585,7 +585,8 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     const bool wino_ups9 = use_wino && a.upsample && !a.gn_scale && winograd_cfg(a) == 66;
     ProfileScope prof(slots_query ? nullptr : ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops,
                       use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops,
-                      (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || (winograd_cfg(a) >= 68 && winograd_cfg(a) <= 74) || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
+                      (use_wino && winograd_cfg(a) == 74) ? PK_WINO_BF3 :
+                      (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || (winograd_cfg(a) >= 68 && winograd_cfg(a) <= 73) || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
 
     if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50 || cfg == 51)) {
         if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)

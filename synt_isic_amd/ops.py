@@ -214,7 +214,7 @@ def denorm_u8(x: torch.Tensor, form="image_generator") -> torch.Tensor:
 
 
 _KINDS = {"conv3x3": 0, "conv1x1": 1, "groupnorm": 2, "attention": 3, "ddpm_step": 4, "other": 5,
-          "conv3x3_winograd_main": 6}
+          "conv3x3_winograd_main": 6, "conv3x3_winograd_bf16x3": 7}
 
 
 def profile_enable(device, on: bool) -> None:

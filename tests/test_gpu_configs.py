@@ -153,9 +153,12 @@ def test_nccl_world1_gather_and_max():
         dist.destroy_process_group()
 
 
+BF3_LAUNCHES_PER_STEP = 30.0      # the stride-1 conv3x3 launches of a step with 64-channel x 16x16-pixel tiles (12 + 9 + 9)
+
+
 def test_bench_line_contract():
     """`python bench.py` (short run, no CPU leg) as the driver starts it: ONE JSON line on stdout carrying the metric of
-    BASELINE.json, a roofline object whose fraction is the executed-MFMA fraction (<= 1 by construction) and the
+    BASELINE.json, a roofline object for the dominant kernel (the bf16x3 Winograd form) and the
     host-inclusive leg; the HIP-event per-launch figures are self-consistent."""
     import json
     import subprocess
@@ -175,9 +178,13 @@ def test_bench_line_contract():
     assert abs(d["value"] - 64.0 / (d["ms_per_step"] * 1e-3 * 1000)) < 1e-6 * d["value"]       # images/sec of a T=1000 run
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
-    assert 0.3 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    # the fp32-equivalent rate against the f32 MFMA peak (the bf16x3 kernel may exceed what the f32 pipe could deliver; its
+    # own pipe's utilisation is reported beside it and is <= 1 by construction)
+    assert 0.3 < rf["frac"] < 2.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
-    assert rf["launches_per_step"] == 31.0 and "traffic" in rf and "traffic_source" in rf
+    bp = rf["bf16_pipe"]
+    assert bp["peak"] == 2500.0 and abs(bp["issued_TFLOPs"] - 6.0 * rf["achieved"]) < 1e-6 * bp["issued_TFLOPs"] and 0.05 < bp["frac"] <= 1.0
+    assert rf["launches_per_step"] == BF3_LAUNCHES_PER_STEP and "traffic" in rf and "traffic_source" in rf
     # (`traffic` and `rocprofv3_avg_launch_us` come from committed profiler files of another run and are labelled so in the
     #  line; comparing a live timing with them belongs to the measurement script, not to a correctness test -- ADVICE r02)
     # the host-inclusive leg has its own step count (>= 256) so that its fixed costs do not pose as the rate
