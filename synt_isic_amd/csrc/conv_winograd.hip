@@ -759,8 +759,8 @@ int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* p
     return launch_winograd_pack_bf3(nullptr, Cout, Cin, packed, s);
 }
 
-// third region: the split filters of the bf16x3 form (conv_winograd_bf3.inc), twice the dwords of the wide layout
-static int64_t winograd_bf3_numel(int Cout, int Cin) { return 2 * winograd_wide_numel(Cout, Cin); }
+// third region: the split filters of the bf16x3 form (conv_winograd_bf3.inc): three bf16 terms = 1.5 dwords per filter value
+static int64_t winograd_bf3_numel(int Cout, int Cin) { return winograd_wide_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin) / 2; }
 int64_t winograd_packed_numel(int Cout, int Cin) {
     return winograd_first_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin) + winograd_bf3_numel(Cout, Cin);
 }

@@ -72,23 +72,26 @@ __device__ __forceinline__ void winograd_pack_wide_elem(size_t i, const float* _
     out[o] = co < cout_pad ? u_first[((size_t)ci * 16 + xi) * cout_pad + co] : 0.0f;
 }
 
-// third packing of U = G g G^T: the A operands of the bf16x3 form's MFMAs, [chunk of 8 ci][position][32-channel block][kind][lane][4 dwords].
-// Lane (co = lane & 31, g = lane >> 5) carries input channels 4 g .. 4 g + 3 of the chunk: dwords 0-1 the first term of
-// channels (1 : 0) and (3 : 2) of the group, dwords 2-3 the second term; kind 0: (U_hi, U_mid), kind 1: (U_hi, U_lo)
+// third packing of U = G g G^T: the A operands of the bf16x3 form's MFMAs, [chunk of 8 ci][position][64-channel tile][768 dwords]:
+// three 1 KB pieces, each one wave-wide 16-byte-per-lane transfer: (U_hi, U_mid) of channel block 0 [64 lanes][4], of block 1,
+// then U_lo of block 0 [64 lanes][2] and of block 1.  Lane (co = lane & 31, g = lane >> 5) of a block carries input channels
+// 4 g .. 4 g + 3 of the chunk; a term's two dwords are channels (1 : 0) and (3 : 2) of the group
 __device__ __forceinline__ void winograd_pack_bf3_elem(size_t i, const float* __restrict__ u_first, int cout_pad, int cout_pad128,
                                                        unsigned* __restrict__ out) {
-    const int n_co32 = cout_pad128 >> 5;
-    const int d = (int)(i & 3), ln = (int)((i >> 2) & 63), kind = (int)((i >> 8) & 1);
-    size_t r = i >> 9;
-    const int blk = (int)(r % n_co32); r /= n_co32;
+    const int n_co64 = cout_pad128 >> 6;
+    const int w = (int)(i % 768);
+    size_t r = i / 768;
+    const int tile = (int)(r % n_co64); r /= n_co64;
     const int pos = (int)(r % 16);
     const int chunk = (int)(r / 16);
-    const int co = 32 * blk + (ln & 31), g = ln >> 5;
-    const int term = (d >> 1) == 0 ? 0 : (kind == 0 ? 1 : 2);           // 0 hi, 1 mid, 2 lo
+    int blk, ln, term, pair;
+    if (w < 512) { blk = w >> 8; ln = (w >> 2) & 63; term = (w >> 1) & 1; pair = w & 1; }       // 0 hi, 1 mid
+    else { blk = (w - 512) >> 7; ln = (w >> 1) & 63; term = 2; pair = w & 1; }                  // 2 lo
+    const int co = 64 * tile + 32 * blk + (ln & 31), g = ln >> 5;
     unsigned pk = 0;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int ci = 8 * chunk + 4 * g + 2 * (d & 1) + e;
+        const int ci = 8 * chunk + 4 * g + 2 * pair + e;
         const float v = co < cout_pad ? u_first[((size_t)ci * 16 + pos) * cout_pad + co] : 0.0f;
         const unsigned hi = __float_as_uint(v) & 0xffff0000u;
         const float r1 = v - __uint_as_float(hi);

@@ -81,7 +81,7 @@ PackJob pack_job_wino_bf3(int Cout, int Cin, float* packed) {           // reads
     PackJob j{}; j.kind = PackJob::WINO_BF3; j.src = packed;
     const size_t wide = (size_t)round_up(Cin, 16) * 16 * round_up(Cout, 128);
     j.dst = packed + winograd_first_floats(Cout, Cin) + wide;
-    j.a = conv_cout_pad(Cout); j.b = round_up(Cout, 128); j.total = 2 * wide; return j;
+    j.a = conv_cout_pad(Cout); j.b = round_up(Cout, 128); j.total = wide + wide / 2; return j;
 }
 
 }  // namespace sisic
