@@ -109,8 +109,7 @@ int sisic_destroy(sisic_ctx* ctx) {
 
 int64_t sisic_conv_packed_numel(int Cout, int Cin, int ksize) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3 && ksize != 7)) return -1;
-    // (1x1: the generic layout followed by conv_pointwise.hip's A-fragment layout, the same number of elements)
-    return (int64_t)conv_cin_pad(Cin, ksize) * ksize * ksize * conv_cout_pad(Cout) * (ksize == 1 ? 2 : 1);
+    return conv_packed_floats(Cout, Cin, ksize);
 }
 
 int sisic_conv_pack_weights(sisic_ctx* ctx, const float* w, int Cout, int Cin, int ksize, float* packed, void* stream) {

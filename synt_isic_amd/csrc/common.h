@@ -122,6 +122,11 @@ constexpr int CONV_CO_TILE = 64;
 inline int conv_ci_chunk(int ksize) { return ksize == 1 ? 32 : (ksize == 3 ? 16 : 4); }   // channel padding of the packed weights (1x1: tiles use 16 or 32)
 inline int conv_cin_pad(int cin, int ksize) { return round_up(cin, conv_ci_chunk(ksize)); }
 inline int conv_cout_pad(int cout) { return round_up(cout, CONV_CO_TILE); }
+// floats of a packed filter: 1x1 filters carry three layouts (pack_device.h: generic, conv_pointwise.hip's, the bf16x3 split)
+inline int64_t conv_packed_floats(int cout, int cin, int ksize) {
+    const int64_t first = (int64_t)conv_cin_pad(cin, ksize) * ksize * ksize * conv_cout_pad(cout);
+    return ksize == 1 ? 3 * first + first / 2 : first;
+}
 
 // launchers implemented in the .hip files
 int launch_conv2d(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
@@ -144,6 +149,9 @@ int conv_stats_slots(const sisic_conv_args& a);
 bool conv_pointwise_applicable(const sisic_conv_args& a);
 int conv_pointwise_stats_slots(const sisic_conv_args& a);
 int launch_conv_pointwise(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
+// conv_pointwise_bf3.hip: the same GEMM with fp32-equivalent products on the bf16 matrix pipe (tile_cfg 28)
+bool conv_pointwise_bf3_applicable(const sisic_conv_args& a);
+int launch_conv_pointwise_bf3(sisic_ctx*, const sisic_conv_args& a, hipStream_t s);
 // mean_rstd (optional, training): [B, groups, 2] = (mean, rstd) of every (sample, group)
 int launch_gn_finalize(sisic_ctx*, const float* st0, int c0, int slots0, const float* st1, int c1, int slots1, int B,
                        int HW, int groups, float eps, const float* gamma, const float* beta, float* scale, float* shift,

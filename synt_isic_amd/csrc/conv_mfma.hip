@@ -423,7 +423,8 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
 // OIHW -> [Cin_pad][KK][cout_pad], zero padded
 __global__ void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, int cin_pad, int cout_pad,
                                  float* __restrict__ out) {
-    const size_t total = (size_t)cin_pad * KK * cout_pad * (KK == 1 ? 2 : 1);      // 1x1: both layouts (pack_device.h)
+    const size_t first = (size_t)cin_pad * KK * cout_pad;
+    const size_t total = KK == 1 ? 3 * first + first / 2 : first;                   // 1x1: all three layouts (pack_device.h)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         conv_pack_elem(i, w, Cout, Cin, KK, cin_pad, cout_pad, out);
     }
@@ -467,7 +468,7 @@ int launch_conv_pack(sisic_ctx*, const float* w, int Cout, int Cin, int k, float
     SISIC_REQUIRE(k == 1 || k == 3 || k == 7, "conv_pack: ksize %d unsupported", k);
     const int cin_pad = conv_cin_pad(Cin, k), cout_pad = conv_cout_pad(Cout);
     const size_t total = (size_t)cin_pad * k * k * cout_pad;
-    const int blocks = (int)std::min<size_t>((total * (k == 1 ? 2 : 1) + 255) / 256, 4096);
+    const int blocks = (int)std::min<size_t>((total * (k == 1 ? 4 : 1) + 255) / 256, 4096);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks), dim3(256), 0, s, w, Cout, Cin, k * k, cin_pad, cout_pad, packed);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
@@ -617,6 +618,14 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         // tile_cfg 20: the lean pointwise kernel (conv_pointwise.hip) for the shapes it takes -- whole 128-pixel tiles and
         // 32-channel chunks -- unless SISIC_POINTWISE=0; the generic tilings below for everything else
         static const bool pw_on = [] { const char* e = std::getenv("SISIC_POINTWISE"); return !e || std::atoi(e) != 0; }();
+        // tile_cfg 28: the same GEMM with fp32-equivalent products on the bf16 matrix pipe (conv_pointwise_bf3.hip) for whole
+        // 64-pixel x 64-channel tiles -- unless SISIC_POINTWISE_BF16X3=0.  (Shape conditions only: an image's bits must not
+        // depend on the batch it is in.)
+        static const bool pwb_on = [] { const char* e = std::getenv("SISIC_POINTWISE_BF16X3"); return !e || std::atoi(e) != 0; }();
+        if ((cfg == 0 && pwb_on && conv_pointwise_bf3_applicable(a)) || (cfg >= 28 && cfg <= 30)) {
+            if (slots_query) { *slots_query = conv_pointwise_stats_slots(a); return SISIC_OK; }
+            return launch_conv_pointwise_bf3(ctx, a, s);
+        }
         if ((cfg == 0 && pw_on && conv_pointwise_applicable(a)) || cfg == 20) {
             if (slots_query) { *slots_query = conv_pointwise_stats_slots(a); return SISIC_OK; }
             return launch_conv_pointwise(ctx, a, s);

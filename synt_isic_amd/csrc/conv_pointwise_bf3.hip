@@ -1,0 +1,380 @@
+// conv_pointwise_bf3.hip -- 1x1 stride-1 convolutions with fp32-EQUIVALENT products on the bf16 matrix pipe (tile_cfg 28).
+//
+// The arithmetic of conv_winograd_bf3.inc applied to the plain GEMM D[co, px] = sum_ci W[co, ci] * act(X[ci, px]): every fp32
+// operand is split exactly into three bf16 terms (hi + mid + lo, 8 + 8 + 8 significant bits), six of the nine term products --
+// all but the three below 2^-24 of the product -- are summed by three v_mfma_f32_32x32x16_bf16 into the fp32 accumulator.
+// Three 32-cycle instructions per 8 input channels replace the four 64-cycle f32 MFMAs of conv_pointwise.hip (tile_cfg 20);
+// the measured error against float64 is the f32 kernels' (tests/test_gpu_kernels.py).
+//
+// A 1x1 convolution has no halo and no transform, so nothing is shared between waves that would be worth a barrier: a WAVE is
+// the unit of work -- 64 (or 32) pixels x 64 output channels of one image -- and runs its whole contraction alone:
+//   B  the lane's own loads: lane = (pixel pair 2 l, 2 l + 1; channel group g): one 8-byte load per channel and chunk of 8
+//      channels gives the group's four channels for both 32-pixel blocks (block = pixel parity); GroupNorm (+ SiLU) and the
+//      split happen in registers and ARE the operand -- with the K grouping of conv_winograd_bf3.inc nothing crosses lanes
+//   A  the split filters straight from global memory in the third region of the packed 1x1 filter (pack_device.h): per chunk
+//      and 32-channel block 16 bytes (hi, mid) + 8 bytes (lo) per lane
+//   the activations one chunk ahead in registers; no LDS but the image's GroupNorm operands (a private table per wave), no
+//   barrier anywhere; four waves per SIMD hide each other's latencies
+//   D  accumulators leave as 8-byte stores (the pixel pair) through a buffer resource: the channel is a scalar offset
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace sisic {
+
+typedef float pwb_f32x16 __attribute__((ext_vector_type(16)));
+typedef short pwb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pwb_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned pwb_u2 __attribute__((ext_vector_type(2)));
+typedef float pwb_f2 __attribute__((ext_vector_type(2)));
+typedef float pwb_f4 __attribute__((ext_vector_type(4)));
+
+struct PwbParams {
+    const float* in0;
+    const float* in1;
+    int c0, c1, B, HW;
+    const float* wb;         // [Cin/8][cout_pad/64][768 dwords] (pack_device.h, conv_pack_elem's third region)
+    int n_co64;
+    const float* bias;
+    int Cout;
+    const float* gn_scale;
+    const float* gn_shift;
+    const float* chan_bias;
+    int chan_bias_stride;
+    const float* residual;
+    int relu;
+    float* out;
+    float* stats;            // optional [B][Cout][HW / 32][4]
+    int n_px, n_co_items, nitems, nwg, nchunks;
+};
+
+constexpr int PWB_WAVES = 4;             // waves (= independent work items) per workgroup
+
+__device__ __forceinline__ float pwb_half_wave_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+    return v + __shfl_xor(v, 16);
+}
+// the first four levels of that tree: the sum over a row of 16 lanes, in every lane of the row
+__device__ __forceinline__ float pwb_row16_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+    return v;
+}
+__device__ __forceinline__ float pwb_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// PRO: 0 = no prologue, 1 = GroupNorm apply, 2 = + SiLU;  NB = 32-pixel blocks per wave: 2 = the lane's pixel PAIR (8-byte
+// loads and stores, block = pixel parity), 1 = one pixel per lane
+template <int PRO, int NB>
+__global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int wg;
+    {   // XCD-aware bijective remap (conv_mfma.hip)
+        const int L = blockIdx.x, nwg = p.nwg;
+        const int xcd = L & 7, slot = L >> 3, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = wg * PWB_WAVES + wave_u;
+    if (item >= p.nitems) return;                                   // (wave-uniform; there is no barrier in this kernel)
+    const int half = lane >> 5, l31 = lane & 31;
+    int co_i = item % p.n_co_items;                                 // output channel item fastest: its waves share the pixels
+    const int t = item / p.n_co_items;
+    int px_t = t % p.n_px, b = t / p.n_px;
+    // (the divisions run on the vector unit; the compiler knows the results are uniform and folds a readfirstlane away, yet
+    //  keeps base pointers and buffer resources derived from them in vector registers -- a waterfall loop around every load)
+    asm volatile("" : "+s"(co_i), "+s"(px_t), "+s"(b));
+    constexpr int CB = 2;                                           // 32-channel blocks per wave
+    const int px0 = 32 * NB * px_t, co0 = 64 * co_i;
+    const int Cin = p.c0 + p.c1, HW = p.HW, n = p.nchunks;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0 + (size_t)b * p.c0 * HW), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in1 ? p.in1 + (size_t)b * p.c1 * HW : p.in0), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wb), 0, -1, 0x00020000);
+
+    // the lane's pixel pair and channel group: channel k of the group is a scalar offset further on
+    const unsigned x_voff = 4u * (unsigned)((4 * half) * HW + px0 + NB * l31);
+    const unsigned a_lane16 = 16u * (unsigned)lane, a_lane8 = 8u * (unsigned)lane;
+
+    float* const gnL = smem + wave_u * (2 * Cin);                   // [input channel][scale, shift] of this wave's image
+    if constexpr (PRO != 0) {
+        for (int i = lane; i < Cin; i += 64) {
+            gnL[2 * i] = p.gn_scale[(size_t)b * Cin + i];
+            gnL[2 * i + 1] = p.gn_shift[(size_t)b * Cin + i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // written and read by this wave only
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    pwb_f32x16 acc[CB][NB];                                         // [channel block][pixel parity]
+#pragma unroll
+    for (int x = 0; x < CB; ++x)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][nb][r] = 0.0f;
+
+    struct XRegs {
+        pwb_f2 x[4];             // channels 4 g .. 4 g + 3 of the chunk, the lane's pixel pair (NB == 1: .x only)
+    };
+    auto ld = [&](const __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+        if constexpr (NB == 2) return __builtin_bit_cast(pwb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs, x_voff, soff, 0));
+        else return pwb_f2{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, x_voff, soff, 0)), 0.0f};
+    };
+    pwb_u4 ua[CB];               // (U_hi, U_mid) of the current chunk
+    pwb_u2 ul[CB];               // U_lo
+    // activations: one chunk ahead in registers (two sets); filters: requested as soon as the previous chunk's MFMAs are
+    // issued -- the SIMD's other waves cover that latency, there is no barrier to hold them back
+    auto load_x = [&](int c, XRegs& r) {
+        const int cc0 = 8 * c;
+        if (cc0 < p.c0) {                                           // the concat seam lies on a chunk boundary (launcher); a
+            const unsigned soff = 4u * (unsigned)(cc0 * HW);        // uniform branch, not a select of the resource (waterfall)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r.x[k] = ld(rs0, soff + 4u * (unsigned)(k * HW));
+        } else {
+            const unsigned soff = 4u * (unsigned)((cc0 - p.c0) * HW);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                r.x[k] = ld(rs1, soff + 4u * (unsigned)(k * HW));
+        }
+    };
+    auto load_a = [&](int c) {
+        const unsigned s0 = 3072u * (unsigned)(c * p.n_co64 + co_i);
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+            ua[x] = __builtin_amdgcn_raw_buffer_load_b128(rsw, a_lane16, s0 + 1024u * (unsigned)x, 0);
+            ul[x] = __builtin_amdgcn_raw_buffer_load_b64(rsw, a_lane8, s0 + 2048u + 512u * (unsigned)x, 0);
+        }
+    };
+    struct Tup { pwb_u4 hm, mh, lh; };                           // the three B operands of a 32-pixel block
+    // GroupNorm (+ SiLU) and the exact split of the lane's four channels of pixel block nb: truncations and exact differences
+    // (plain vector instructions on purpose: packed-f32 ones are not hidden by the bf16 MFMA, tools/bf16_issue_probe.hip)
+    auto make = [&](int c, const XRegs& r, int nb) {
+        pwb_f4 g01 = {1.0f, 0.0f, 1.0f, 0.0f}, g23 = g01;          // (scale, shift) of channels 0, 1 and 2, 3 of the lane's group
+        if constexpr (PRO != 0) {
+            const float* gp = gnL + 2 * (8 * c + 4 * half);
+            g01 = *reinterpret_cast<const pwb_f4*>(gp);
+            g23 = *reinterpret_cast<const pwb_f4*>(gp + 4);
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float e = nb ? r.x[k].y : r.x[k].x;
+            if constexpr (PRO != 0) {
+                const float sc = k == 0 ? g01.x : (k == 1 ? g01.z : (k == 2 ? g23.x : g23.z));
+                const float sh = k == 0 ? g01.y : (k == 1 ? g01.w : (k == 2 ? g23.y : g23.w));
+                e = e * sc + sh;
+                if constexpr (PRO == 2) e = pwb_silu(e);
+            }
+            v[k] = e;
+        }
+        unsigned hi[2], mid[2], lo[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float v0 = v[2 * q], v1 = v[2 * q + 1];
+            const unsigned h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+            const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+            const unsigned m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+            const float l0 = r0 - __uint_as_float(m0), l1 = r1 - __uint_as_float(m1);
+            hi[q] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+            mid[q] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+            lo[q] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+        }
+        return Tup{pwb_u4{hi[0], hi[1], mid[0], mid[1]}, pwb_u4{mid[0], mid[1], hi[0], hi[1]}, pwb_u4{lo[0], lo[1], hi[0], hi[1]}};
+    };
+    auto mm = [&](const Tup& t, auto nb_tag) {
+        constexpr int nb = decltype(nb_tag)::value;
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+            const pwb_u4 a_hl = {ua[x].x, ua[x].y, ul[x].x, ul[x].y};
+            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, ua[x]), __builtin_bit_cast(pwb_bf16x8, t.hm), acc[x][nb], 0, 0, 0);
+            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, ua[x]), __builtin_bit_cast(pwb_bf16x8, t.mh), acc[x][nb], 0, 0, 0);
+            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, a_hl), __builtin_bit_cast(pwb_bf16x8, t.lh), acc[x][nb], 0, 0, 0);
+        }
+    };
+    using Z = std::integral_constant<int, 0>;
+    using O = std::integral_constant<int, 1>;
+
+    XRegs ra, rb;
+    load_x(0, ra);
+    load_a(0);
+    if constexpr (NB == 2) {
+        auto compute = [&](int c, const XRegs& r) {
+            mm(make(c, r, 0), Z{});
+            mm(make(c, r, 1), O{});
+        };
+        int c = 0;
+        for (; c + 1 < n; c += 2) {
+            load_x(c + 1, rb);
+            compute(c, ra);
+            load_a(c + 1);
+            if (c + 2 < n) load_x(c + 2, ra);
+            compute(c + 1, rb);
+            if (c + 2 < n) load_a(c + 2);
+        }
+        if (c < n) compute(c, ra);
+    } else {
+        // one pixel block per wave leaves registers for a software pipeline: the operands of chunk c + 1 are put together
+        // BETWEEN the MFMAs of chunk c (a wave issues in order: vector work behind six MFMAs waits for all of them)
+        auto weave = [&]() {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);       // eight vector instructions
+            }
+        };
+        if (n > 1) load_x(1, rb);
+        Tup t = make(0, ra, 0);
+        int c = 0;
+        for (; c + 2 < n; c += 2) {
+            load_x(c + 2, ra);
+            Tup u = make(c + 1, rb, 0);
+            mm(t, Z{});
+            weave();
+            load_a(c + 1);
+            if (c + 3 < n) load_x(c + 3, rb);
+            t = make(c + 2, ra, 0);
+            mm(u, Z{});
+            weave();
+            load_a(c + 2);
+        }
+        if (c + 1 < n) {
+            Tup u = make(c + 1, rb, 0);
+            mm(t, Z{});
+            load_a(c + 1);
+            mm(u, Z{});
+        } else {
+            mm(t, Z{});
+        }
+    }
+
+    // ---- epilogue: bias + per-sample channel bias + residual, NCHW stores of the pixel pair; GroupNorm partials (one slot
+    // per 32 consecutive pixels)
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.Cout * HW, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual + (size_t)b * p.Cout * HW : p.out), 0, -1, 0x00020000);
+    const unsigned o_voff = 4u * (unsigned)((4 * half) * HW + px0 + NB * l31);
+    const int slots = HW / 32;
+#pragma unroll
+    for (int x = 0; x < CB; ++x) {
+        // (all residual / bias operands of the block are requested before the first is used)
+        float add[16];
+        pwb_f2 res[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cs = co0 + 32 * x + 8 * (r >> 2) + (r & 3);          // + 4 half: the lane's part
+            const int col = cs + 4 * half;
+            add[r] = 0.0f;
+            if (p.bias) add[r] += p.bias[col];
+            if (p.chan_bias) add[r] += p.chan_bias[(size_t)b * p.chan_bias_stride + col];
+            res[r] = pwb_f2{0.0f, 0.0f};
+            if (p.residual) {
+                if constexpr (NB == 2) res[r] = __builtin_bit_cast(pwb_f2, __builtin_amdgcn_raw_buffer_load_b64(rsr, o_voff, 4u * (unsigned)(cs * HW), 0));
+                else res[r].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, o_voff, 4u * (unsigned)(cs * HW), 0));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cs = co0 + 32 * x + 8 * (r >> 2) + (r & 3);
+            float vv[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                vv[nb] = acc[x][nb][r] + add[r] + (nb ? res[r].y : res[r].x);
+                if (p.relu) vv[nb] = fmaxf(vv[nb], 0.0f);
+            }
+            if constexpr (NB == 2) __builtin_amdgcn_raw_buffer_store_b64(pwb_u2{__float_as_uint(vv[0]), __float_as_uint(vv[1])}, rso, o_voff, 4u * (unsigned)(cs * HW), 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[0]), rso, o_voff, 4u * (unsigned)(cs * HW), 0);
+            if (p.stats) {
+                // a slot = 32 CONSECUTIVE pixels, summed over the same binary tree (pairs, fours, ... of neighbours) in both
+                // forms, so that the partials -- and the GroupNorm of the next layer -- do not depend on the form, i.e. on the
+                // batch: one pixel per lane: five lane levels; a pixel pair per lane: the pair, then four lane levels
+                const int co = cs + 4 * half;
+                if constexpr (NB == 1) {
+                    const float s1 = pwb_half_wave_sum(vv[0]);
+                    const float d = vv[0] - s1 * (1.0f / 32.0f);
+                    float dd;                  // the ROUNDED square (the compiler would fuse it into the first add of the tree, in
+                    asm volatile("v_mul_f32 %0, %1, %1" : "=v"(dd) : "v"(d));       // one lane of each pair only)
+                    const float q = pwb_half_wave_sum(dd);
+                    if (l31 == 0)
+                        reinterpret_cast<float4*>(p.stats)[((size_t)b * p.Cout + co) * slots + px_t] = make_float4(32.0f, s1, q, 0.0f);
+                } else {
+                    const float s1 = pwb_row16_sum(vv[0] + vv[1]);
+                    const float mean = s1 * (1.0f / 32.0f);
+                    const float d0 = vv[0] - mean, d1 = vv[1] - mean;
+                    float q0, q1;              // two ROUNDED squares as in the other form (the compiler would fuse one into an fma)
+                    asm volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %3, %3" : "=&v"(q0), "=&v"(q1) : "v"(d0), "v"(d1));
+                    const float q = pwb_row16_sum(q0 + q1);
+                    if ((l31 & 15) == 0)
+                        reinterpret_cast<float4*>(p.stats)[((size_t)b * p.Cout + co) * slots + 2 * px_t + (l31 >> 4)] = make_float4(32.0f, s1, q, 0.0f);
+                }
+            }
+        }
+    }
+}
+
+// The shapes this kernel takes: whole 64-pixel and 64-channel tiles, whole 8-channel chunks with the concat seam on a chunk
+// boundary, 8-byte aligned pixel pairs, 32-bit byte offsets inside an image of either operand and inside the filter tensor.
+bool conv_pointwise_bf3_applicable(const sisic_conv_args& a) {
+    if (a.ksize != 1 || a.stride != 1 || a.upsample) return false;
+    const int HW = a.Hin * a.Win, Cin = a.c0 + a.c1;
+    if (HW % 64 != 0 || Cin % 8 != 0 || (a.c1 != 0 && a.c0 % 8 != 0) || a.Cout % 64 != 0) return false;
+    if (((reinterpret_cast<uintptr_t>(a.in0) | reinterpret_cast<uintptr_t>(a.in1) | reinterpret_cast<uintptr_t>(a.out) |
+          reinterpret_cast<uintptr_t>(a.residual)) & 7) != 0) return false;
+    if (4.0 * std::max(std::max(a.c0, a.c1), a.Cout) * HW >= 4294967296.0 || 6.0 * conv_cin_pad(Cin, 1) * conv_cout_pad(a.Cout) >= 4294967296.0) return false;
+    if (a.gn_scale && Cin > 1024) return false;               // GroupNorm operands of an image: a table per wave in LDS
+    return true;
+}
+
+template <int PRO, int NB>
+static int launch_pwb(sisic_ctx* ctx, PwbParams& p, int Cin, hipStream_t s) {
+    p.n_co_items = p.Cout / 64;
+    p.n_px = p.HW / (32 * NB);
+    const int64_t nitems = (int64_t)p.B * p.n_px * p.n_co_items;
+    SISIC_REQUIRE(nitems > 0 && nitems < (int64_t(1) << 31), "conv2d(pointwise bf16x3): grid too large");
+    p.nitems = (int)nitems;
+    p.nwg = (int)((nitems + PWB_WAVES - 1) / PWB_WAVES);
+    const size_t lds = PRO ? sizeof(float) * (size_t)(PWB_WAVES * 2 * Cin) : 0;
+    static std::atomic<uint64_t> opt{0};
+    auto kern = conv_pwb_kernel<PRO, NB>;
+    SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)lds, opt));
+    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(64 * PWB_WAVES), lds, s, p);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+int launch_conv_pointwise_bf3(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t s) {
+    SISIC_REQUIRE(conv_pointwise_bf3_applicable(a), "conv2d(pointwise bf16x3): shape not supported by tile_cfg 28");
+    PwbParams p{};
+    const int Cin = a.c0 + a.c1;
+    p.in0 = a.in0; p.in1 = a.in1; p.c0 = a.c0; p.c1 = a.c1; p.B = a.B; p.HW = a.Hin * a.Win;
+    p.wb = a.w_packed + 2 * (size_t)conv_cin_pad(Cin, 1) * conv_cout_pad(a.Cout);      // the third layout (pack_device.h)
+    p.n_co64 = conv_cout_pad(a.Cout) / 64;
+    p.bias = a.bias; p.Cout = a.Cout;
+    p.gn_scale = a.gn_scale; p.gn_shift = a.gn_shift;
+    p.chan_bias = a.chan_bias; p.chan_bias_stride = a.chan_bias_stride; p.residual = a.residual; p.relu = a.relu;
+    p.out = a.out; p.stats = a.stats_out;
+    p.nchunks = Cin / 8;
+    const int pro = a.gn_scale == nullptr ? 0 : (a.gn_silu ? 2 : 1);
+    // 64-pixel items where they give every SIMD at least two waves (1024 SIMDs), 32-pixel items otherwise: a lone wave has
+    // nobody to hide its latencies.  (The choice depends on the batch; the bits of an output do not: its chain of MFMAs is the same.)
+    // (tile_cfg 29 / 30 force the 32- / 64-pixel form: tests of their bit-equality)
+    const bool wide = a.tile_cfg == 29 ? false : (a.tile_cfg == 30 ? true : (int64_t)a.B * (p.HW / 64) * (a.Cout / 64) >= 2048);
+    if (wide) {
+        if (pro == 2) return launch_pwb<2, 2>(ctx, p, Cin, s);
+        if (pro == 1) return launch_pwb<1, 2>(ctx, p, Cin, s);
+        return launch_pwb<0, 2>(ctx, p, Cin, s);
+    }
+    if (pro == 2) return launch_pwb<2, 1>(ctx, p, Cin, s);
+    if (pro == 1) return launch_pwb<1, 1>(ctx, p, Cin, s);
+    return launch_pwb<0, 1>(ctx, p, Cin, s);
+}
+
+}  // namespace sisic

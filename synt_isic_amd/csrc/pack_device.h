@@ -6,13 +6,43 @@
 
 namespace sisic {
 
-// OIHW -> [Cin_pad][KK][cout_pad], zero padded (conv_mfma.hip).  1x1 filters carry a second layout behind the first (twice
-// the elements): [8-channel chunk][32-channel block][lane = (ci & 1) * 32 + co % 32][(ci % 8) / 2] -- the A fragments of
-// conv_pointwise.hip, one 16-byte load per lane and 8 input channels.
+// OIHW -> [Cin_pad][KK][cout_pad], zero padded (conv_mfma.hip).  1x1 filters carry two more layouts behind the first
+// (conv_packed_floats(), common.h: 3.5 times the elements):
+//   second  [8-channel chunk][32-channel block][lane = (ci & 1) * 32 + co % 32][(ci % 8) / 2] -- the A fragments of
+//           conv_pointwise.hip, one 16-byte load per lane and 8 input channels;
+//   third   [8-channel chunk][64-channel tile][768 dwords] -- the filter split into three bf16 terms, the A operands of
+//           conv_pointwise_bf3.hip: (hi, mid) of channel block 0 [64 lanes][4 dwords], of block 1, then lo of block 0
+//           [64 lanes][2] and of block 1; lane (co = lane & 31, g = lane >> 5) carries input channels 4 g .. 4 g + 3 of the
+//           chunk, a term's two dwords are channels (1 : 0) and (3 : 2) of the group (as winograd_pack_bf3_elem below).
 __device__ __forceinline__ void conv_pack_elem(size_t i, const float* __restrict__ w, int Cout, int Cin, int KK, int cin_pad,
                                                int cout_pad, float* __restrict__ out) {
     const size_t first = (size_t)cin_pad * KK * cout_pad;
-    if (i >= first) {                   // (KK == 1 only: the callers iterate 2 * first elements then)
+    if (i >= 2 * first) {               // (KK == 1 only) third layout
+        const size_t j = i - 2 * first;
+        const int n_co64 = cout_pad >> 6;
+        const int wd = (int)(j % 768);
+        const size_t r = j / 768;
+        const int tile = (int)(r % n_co64), chunk = (int)(r / n_co64);
+        int blk, ln, term, pair;
+        if (wd < 512) { blk = wd >> 8; ln = (wd >> 2) & 63; term = (wd >> 1) & 1; pair = wd & 1; }      // 0 hi, 1 mid
+        else { blk = (wd - 512) >> 7; ln = (wd >> 1) & 63; term = 2; pair = wd & 1; }                   // 2 lo
+        const int co = 64 * tile + 32 * blk + (ln & 31), g = ln >> 5;
+        unsigned pk = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ci = 8 * chunk + 4 * g + 2 * pair + e;
+            const float v = (co < Cout && ci < Cin) ? w[(size_t)co * Cin + ci] : 0.0f;
+            const unsigned hi = __float_as_uint(v) & 0xffff0000u;
+            const float r1 = v - __uint_as_float(hi);
+            const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(mid);
+            const unsigned t = term == 0 ? hi : (term == 1 ? mid : __float_as_uint(r2));
+            pk |= (t >> 16) << (16 * e);
+        }
+        out[i] = __uint_as_float(pk);
+        return;
+    }
+    if (i >= first) {                   // (KK == 1 only) second layout
         const size_t j = i - first;
         const int s = (int)(j & 3), ln = (int)((j >> 2) & 63);
         const size_t blk = j >> 8;

@@ -65,7 +65,7 @@ PackJob pack_job_flip(const float* w, int Cout, int Cin, int KK, float* wt) {
 }
 PackJob pack_job_conv(const float* w, int Cout, int Cin, int k, float* packed) {
     PackJob j{}; j.kind = PackJob::CONV_PACK; j.src = w; j.dst = packed; j.a = Cout; j.b = Cin; j.c = k * k;
-    j.d = conv_cin_pad(Cin, k); j.e = conv_cout_pad(Cout); j.total = (size_t)j.d * j.c * j.e * (k == 1 ? 2 : 1);      // 1x1: both layouts
+    j.d = conv_cin_pad(Cin, k); j.e = conv_cout_pad(Cout); j.total = (size_t)conv_packed_floats(Cout, Cin, k);      // 1x1: all three layouts
     return j;
 }
 PackJob pack_job_wino_first(const float* w, int Cout, int Cin, float* packed) {

@@ -43,7 +43,7 @@ def test_abi_version_and_error_channel(lib):
     assert b"sisic_create" in lib.sisic_last_error()
     assert lib.sisic_conv_packed_numel(64, 3, 3) == 16 * 9 * 64
     assert lib.sisic_conv_packed_numel(3, 64, 3) == 64 * 9 * 64
-    assert lib.sisic_conv_packed_numel(768, 256, 1) == 2 * 256 * 768      # 1x1: the direct kernel's layout and the pointwise kernel's behind it
+    assert lib.sisic_conv_packed_numel(768, 256, 1) == 256 * 768 * 7 // 2     # 1x1: the direct kernel's layout, the pointwise kernel's and the bf16x3 split behind it
     assert lib.sisic_conv_packed_numel(64, 64, 5) == -1
 
 

@@ -379,7 +379,7 @@ def test_conv1x1(cfg, H, W):
 def test_conv1x1_pointwise(B, c0, c1, cout, H, W):
     """tile_cfg 20 (conv_pointwise.hip): the lean 1x1 kernel -- filters straight into registers from their second packing,
     32-channel chunks of the input through LDS -- against the float64 convolution with every fused feature, bit-equal to
-    the generic kernel (same FMA chain in the same channel order), taken by the auto dispatch, and refusing ragged shapes."""
+    the generic kernel (same FMA chain in the same channel order), and refusing ragged shapes."""
     from synt_isic_amd import ops
     x = _rand(B, c0, H, W, seed=400)
     x2 = _rand(B, c1, H, W, seed=401) if c1 else None
@@ -392,7 +392,10 @@ def test_conv1x1_pointwise(B, c0, c1, cout, H, W):
                dict(x2=x2, gn=gn, gn_silu=True, chan_bias=cb, relu=True)):
         y = _run_conv(x, w, 20, **kw)
         _close(y, _conv_ref(x, w, **kw), what="pointwise conv1x1")
-        assert torch.equal(y, _run_conv(x, w, 25, **kw)) and torch.equal(y, _run_conv(x, w, 0, **kw))
+        assert torch.equal(y, _run_conv(x, w, 25, **kw))
+        # the auto dispatch: the bf16x3 kernel (tile_cfg 28) where its 64-pixel x 64-channel tiles are whole, this one otherwise
+        bf3 = cout % 64 == 0 and (H * W) % 64 == 0 and (c0 + c1) % 8 == 0 and c0 % 8 == 0
+        assert torch.equal(_run_conv(x, w, 0, **kw), _run_conv(x, w, 28, **kw) if bf3 else y)
     # GroupNorm partials of the result: one slot per 32 pixels
     d = lambda t: None if t is None else t.to(DEV).contiguous()
     y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 1, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=20, with_stats=True)
@@ -407,6 +410,66 @@ def test_conv1x1_pointwise(B, c0, c1, cout, H, W):
     from synt_isic_amd._lib import SisicError
     with pytest.raises(SisicError, match="pointwise"):
         _run_conv(_rand(1, 40, 8, 8, seed=410), _rand(64, 40, 1, 1, seed=411), 20)       # 40 channels, 64 pixels
+
+
+@pytest.mark.parametrize("B,c0,c1,cout,H,W", [(2, 64, 0, 128, 32, 32), (3, 128, 64, 64, 16, 16), (2, 256, 128, 128, 8, 16),
+                                              (2, 256, 0, 768, 16, 16), (1, 8, 0, 64, 8, 8), (2, 40, 24, 192, 8, 24)])
+def test_conv1x1_pointwise_bf16x3(B, c0, c1, cout, H, W):
+    """tile_cfg 28 (conv_pointwise_bf3.hip): the 1x1 GEMM with fp32-equivalent products on the bf16 matrix pipe (three exact
+    bf16 terms per operand, six products, fp32 accumulate) -- against the float64 convolution with every fused feature at the
+    SAME bound as the f32 kernels, its GroupNorm partials, and refusing ragged shapes."""
+    from synt_isic_amd import ops
+    x = _rand(B, c0, H, W, seed=420)
+    x2 = _rand(B, c1, H, W, seed=421) if c1 else None
+    w = _rand(cout, c0 + c1, 1, 1, seed=422, scale=(c0 + c1) ** -0.5)
+    b = _rand(cout, seed=423)
+    res = _rand(B, cout, H, W, seed=424)
+    cb = _rand(B, cout, seed=425)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=426), 0.3 * _rand(B, c0 + c1, seed=427))
+    for kw in (dict(bias=b, x2=x2), dict(bias=b, x2=x2, gn=gn, gn_silu=False, residual=res),
+               dict(x2=x2, gn=gn, gn_silu=True, chan_bias=cb, relu=True)):
+        _close(_run_conv(x, w, 28, **kw), _conv_ref(x, w, **kw), what="bf16x3 pointwise conv1x1")
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 1, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=28, with_stats=True)
+    assert st is not None and tuple(st.shape) == (B, cout, H * W // 32, 4)
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=428), 0.1 * _rand(cout, seed=429)
+    sc, sh = ops.groupnorm_finalize(st, H * W, d(gamma), d(beta), 32, 1e-5)
+    yc = y.cpu().double()
+    ref = F.group_norm(yc, 32, gamma.double(), beta.double(), 1e-5)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=KTOL, what="groupnorm from the bf16x3 pointwise kernel's partials")
+    from synt_isic_amd._lib import SisicError
+    with pytest.raises(SisicError, match="pointwise bf16x3"):
+        _run_conv(_rand(1, 40, 8, 8, seed=430), _rand(70, 40, 1, 1, seed=431), 28)       # 70 output channels
+
+
+def test_conv1x1_pointwise_bf16x3_item_width_does_not_change_bits():
+    """The kernel gives a wave 64 pixels when that still leaves every SIMD two waves, 32 otherwise -- a choice that
+    depends on the batch.  An image's bits must not: the same image alone (32-pixel items) and inside a batch of 16
+    (64-pixel items) comes out bit-equal."""
+    B, cin, cout, H, W = 16, 64, 512, 32, 32            # 16 x 16 x 8 = 2048 wide items
+    x = _rand(B, cin, H, W, seed=440)
+    w = _rand(cout, cin, 1, 1, seed=441, scale=cin ** -0.5)
+    b = _rand(cout, seed=442)
+    gn = (1.0 + 0.3 * _rand(B, cin, seed=443), 0.3 * _rand(B, cin, seed=444))
+    y = _run_conv(x, w, 28, bias=b, gn=gn, gn_silu=False)
+    y0 = _run_conv(x[:1].contiguous(), w, 28, bias=b, gn=(gn[0][:1].contiguous(), gn[1][:1].contiguous()), gn_silu=False)
+    assert torch.equal(y[:1], y0)
+    _close(y, _conv_ref(x, w, bias=b, gn=gn, gn_silu=False), what="bf16x3 pointwise conv1x1, wide items")
+    # ... and neither do its GroupNorm partials (they decide the next layer's normalisation): slot = 32 consecutive pixels,
+    # one summation tree in both forms
+    from synt_isic_amd import ops
+    d = lambda t: t.to(DEV).contiguous()
+    wp = ops.pack_conv_weight(d(w))
+    _, st = ops.conv2d(d(x), wp, cout, 1, bias=d(b), tile_cfg=28, with_stats=True)
+    _, st0 = ops.conv2d(d(x[:1]), wp, cout, 1, bias=d(b), tile_cfg=28, with_stats=True)
+    assert torch.equal(st[:1], st0)
+    # the two forms forced (tile_cfg 29: 32 pixels per wave, 30: 64) on one input, every fused feature
+    res, cb = d(_rand(B, cout, H, W, seed=445)), d(_rand(B, cout, seed=446))
+    for kw in (dict(), dict(residual=res, relu=True), dict(chan_bias=cb, gn_scale=d(gn[0]), gn_shift=d(gn[1]), gn_silu=True)):
+        ya, sa = ops.conv2d(d(x), wp, cout, 1, bias=d(b), tile_cfg=29, with_stats=True, **kw)
+        yb, sb = ops.conv2d(d(x), wp, cout, 1, bias=d(b), tile_cfg=30, with_stats=True, **kw)
+        assert torch.equal(ya, yb) and torch.equal(sa, sb)
 
 
 def test_conv_reference_layer_shapes():
