@@ -14,7 +14,9 @@
 //   A  the split filters straight from global memory in the third region of the packed 1x1 filter (pack_device.h): per chunk
 //      and 32-channel block 16 bytes (hi, mid) + 8 bytes (lo) per lane
 //   the activations one chunk ahead in registers; no LDS but the image's GroupNorm operands (a private table per wave), no
-//   barrier anywhere; four waves per SIMD hide each other's latencies
+//   barrier anywhere; four waves per SIMD hide each other's latencies.  (Measured and not kept, profiles/r03/
+//   conv_bench_pointwise_bf16x3_variants.txt: the filter chunk fetched once per 4-wave workgroup into LDS, activations four
+//   chunks ahead -- within 3 % of this form on every layer.)
 //   D  accumulators leave as 8-byte stores (the pixel pair) through a buffer resource: the channel is a scalar offset
 #include <cstdlib>
 #include <type_traits>

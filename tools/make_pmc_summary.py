@@ -39,6 +39,8 @@ def main():
     conv_calls = 0
     main_bytes = 0.0
     main_calls = 0
+    bf3_bytes = 0.0
+    bf3_calls = 0
     for name, (n, v) in sorted(sq.items()):
         if not name.startswith("sisic::"):
             continue
@@ -65,7 +67,10 @@ def main():
         if is_main:
             main_bytes += (rd + wb) * n
             main_calls += n
-        is_conv3 = ("conv_winograd_kernel" in name or "conv_winograd_wide_kernel" in name or "conv_winograd_col_kernel" in name or re.search(r"conv_mfma_kernel<3,", name) or
+        if "conv_winograd_bf3_kernel" in name:         # the bf16x3 form: profile slot "conv3x3_winograd_bf16x3", the dominant kernel
+            bf3_bytes += (rd + wb) * n
+            bf3_calls += n
+        is_conv3 = ("conv_winograd_kernel" in name or "conv_winograd_wide_kernel" in name or "conv_winograd_col_kernel" in name or "conv_winograd_bf3_kernel" in name or re.search(r"conv_mfma_kernel<3,", name) or
                     "conv3x3_smallcout" in name or "splitk_reduce" in name)
         if is_conv3:
             conv_bytes += (rd + wb) * n
@@ -76,6 +81,9 @@ def main():
     summary["_winograd_main"] = {"hbm_MB_per_launch": main_bytes / max(main_calls, 1) / 1e6, "launches": main_calls,
                                  "note": "HBM bytes per launch of the stride-1 F(2x2,3x3) kernels (conv_winograd_col_kernel<128,16>, <64,8>; "
                                          "earlier rounds: conv_winograd_wide_kernel, conv_winograd_kernel<1,8,8,*,16,false>) = bench.py roofline.traffic"}
+    summary["_winograd_bf16x3"] = {"hbm_MB_per_launch": bf3_bytes / max(bf3_calls, 1) / 1e6, "launches": bf3_calls,
+                                   "note": "HBM bytes per launch of conv_winograd_bf3_kernel<PRO> = bench.py roofline.traffic when that "
+                                           "kernel is the dominant one"}
     with open(dst, "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print(json.dumps(summary["_conv3x3_all"]))

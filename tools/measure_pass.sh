@@ -18,3 +18,22 @@ cd $R && bash tools/prof_pmc.sh sq SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ
 cd $R && bash tools/prof_pmc.sh fetch FETCH_SIZE GRBM_GUI_ACTIVE | cut -c1-200 | head -6
 cd $R && bash tools/prof_pmc.sh write WRITE_SIZE | cut -c1-200 | head -6
 cd $R && python tools/make_pmc_summary.py gpurun_out gpurun_out/pmc_summary_r03.json
+# per-layer: the bf16x3 kernels against the f32 forms they replace (B = 64), the per-wave timeline of the bf16x3 Winograd kernel,
+# the training step and batch-1 latency with the round's final library
+cd $R
+{ echo "# python tools/conv_bench.py --cfgs 70|71,74: every stride-1 3x3 layer with whole 16x16-pixel tiles, third f32 Winograd form vs the bf16x3 form"
+  timeout -k 10 300 python tools/conv_bench.py --cfgs 71,74 --match "@64 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
+  timeout -k 10 300 python tools/conv_bench.py --cfgs 70,74 --match "@32 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
+  timeout -k 10 300 python tools/conv_bench.py --cfgs 70,74 --match "@16 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
+  echo "# python tools/conv_bench.py --cfgs 20,28 --match 1x1: the 1x1 layers, f32 pointwise kernel vs the bf16x3 pointwise kernel"
+  timeout -k 10 300 python tools/conv_bench.py --cfgs 20,28 --match "1x1" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"; } > gpurun_out/conv_bench_bf16x3.txt || exit 1
+tail -3 gpurun_out/conv_bench_bf16x3.txt
+if [ -f tools/bin/libsisic_hip_timing.so ]; then
+    { SISIC_LIB_PATH=$R/tools/bin/libsisic_hip_timing.so timeout -k 10 200 python tools/bf3_timeline.py --cin 64 2>&1 | grep -v amdgpu
+      SISIC_LIB_PATH=$R/tools/bin/libsisic_hip_timing.so timeout -k 10 200 python tools/bf3_timeline.py --cin 128 --cout 128 --hw 32 2>&1 | grep -v amdgpu
+      SISIC_LIB_PATH=$R/tools/bin/libsisic_hip_timing.so timeout -k 10 200 python tools/bf3_timeline.py --cin 256 --cout 256 --hw 16 2>&1 | grep -v amdgpu; } > gpurun_out/bf3_timeline.txt || exit 1
+fi
+timeout -k 10 400 python tools/train_bench.py > gpurun_out/train_bench.txt 2> gpurun_out/train_bench.log || { tail -5 gpurun_out/train_bench.log; exit 1; }
+cat gpurun_out/train_bench.txt
+timeout -k 10 300 python tools/bench_configs.py > gpurun_out/configs_4_5.jsonl 2> gpurun_out/configs_4_5.log || { tail -5 gpurun_out/configs_4_5.log; exit 1; }
+cut -c1-300 gpurun_out/configs_4_5.jsonl
