@@ -193,7 +193,9 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
     // inside each branch, which serialises the whole prefetch (cdna_hip_programming.md, .s-level trap c).
     const int prologue = (p.gn_scale == nullptr) ? 0 : (p.gn_silu ? 2 : 1);   // wave-uniform
 
-    auto load_chunk = [&](int chunk) {
+    // (always_inline: called from two instances of `step`, the 7x7 instance's compute_chunk was left as a function of its own --
+    //  its accumulators went through memory and config 5 ran four times slower until tools/bench_configs.py was run again)
+    auto load_chunk = [&](int chunk) __attribute__((always_inline)) {
         const int c = chunk * CIC + sci;
         cval = c < Cin;
         const int cc = min(c, Cin - 1);
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
     };
 
     // (buf is a compile-time constant in the channel loop below: no buffer-parity arithmetic in the operand addresses)
-    auto store_chunk = [&](const int buf) {
+    auto store_chunk = [&](const int buf) __attribute__((always_inline)) {
         float* dst = in_lds + buf * G::IN_BUF + sci * G::CHS + sl;
         const unsigned m = cval ? vmask : 0u;       // padding / missing channels stay zero AFTER the prologue
         float v[G::EPT];
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
                 make_float4(rw[4 * i + 0], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]);
     };
 
-    auto compute_chunk = [&](const int buf) {
+    auto compute_chunk = [&](const int buf) __attribute__((always_inline)) {
         const float* A = w_lds + buf * G::W_BUF + a_base;
         const float* Bm = in_lds + buf * G::IN_BUF + b_base;
 #pragma unroll
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(64 * WM * WN * KSP, OCC) conv_mfma_kernel(cons
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
-    auto step = [&](const int chunk, auto buf_tag) {
+    auto step = [&](const int chunk, auto buf_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(buf_tag)::value;
         const bool more = chunk + 1 < p.nchunks;
         if (more) load_chunk(chunk + 1);
