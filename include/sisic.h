@@ -83,7 +83,9 @@ typedef struct sisic_conv_args {
     float* out;             /* dev [B,Cout,Hout,Wout]                     */
     int tile_cfg;           /* 0 = auto; >0 forces a tile configuration (tests/tuning) */
     const float* w_winograd; /* dev, layout of sisic_conv_winograd_pack, or NULL: when given, 3x3 stride-1
-                                convolutions may run as Winograd F(2x2,3x3) (tile_cfg 60/61 force it)        */
+                                convolutions may run as Winograd F(2x2,3x3) (tile_cfg 60..74 force a form; 74 = the
+                                fp32-equivalent bf16x3 form, the automatic choice for whole 64-channel x 16x16-pixel
+                                tiles; 1x1: tile_cfg 28 = the bf16x3 pointwise kernel, 20 = the f32 one)             */
     float* stats_out;        /* dev [B,Cout,slots,4] or NULL: each workgroup also writes (count, sum, sum of squared
                                 deviations from its own mean, 0) of the values it stored, per image and channel, so that the GroupNorm
                                 that follows needs sisic_groupnorm_finalize only (no second pass over `out`).
