@@ -306,7 +306,7 @@ def test_conv3x3_winograd_reference_layers_and_identity():
         ww = _rand(cout, cin, 3, 3, seed=140 + i, scale=(cin * 9) ** -0.5)
         bb = _rand(cout, seed=150 + i, scale=0.1)
         outs = {}
-        for cfg in (60, 62, 66, 70, 71, 72, 73):
+        for cfg in (60, 62, 66, 70, 71, 72, 73, 74):       # 74: the bf16x3 form -- same bound, other bits
             outs[cfg] = _run_wino(xx, ww, cfg, bias=bb)
             _close(outs[cfg], _conv_ref(xx, ww, bb), what=f"winograd{cfg} layer {cin}->{cout}@{r}")
         # the second geometry (filters from global memory into registers, 32 tiles per workgroup; 72 / 73) and the third
@@ -324,6 +324,7 @@ def test_conv3x3_winograd_reference_layers_and_identity():
         fused = {cfg: _run_wino(x1, w2, cfg, **kw) for cfg in (66, 70, 71, 72, 73)}
         for cfg in (70, 71, 72, 73):
             assert torch.equal(fused[cfg], fused[66]), ("fused", cfg)
+        _close(_run_wino(x1, w2, 74, **kw), _conv_ref(x1, w2, **kw), tol=KTOL, what=f"winograd74 fused layer {cin}+24->{cout}@{r}")
     from synt_isic_amd import ops
     from synt_isic_amd._lib import SisicError
     with pytest.raises(SisicError, match="w_winograd"):
@@ -441,6 +442,23 @@ def test_conv1x1_pointwise_bf16x3(B, c0, c1, cout, H, W):
     from synt_isic_amd._lib import SisicError
     with pytest.raises(SisicError, match="pointwise bf16x3"):
         _run_conv(_rand(1, 40, 8, 8, seed=430), _rand(70, 40, 1, 1, seed=431), 28)       # 70 output channels
+
+
+@pytest.mark.parametrize("cin", [8, 16, 24, 40, 48, 56, 72, 104])
+def test_bf16x3_kernels_every_loop_tail(cin):
+    """The channel loops of the two bf16x3 kernels are unrolled and software-pipelined (Winograd: first body, pairs of steady
+    bodies, up to four tail bodies; pointwise: operands a chunk ahead, two bodies per iteration): 1, 2, 3, 5, 6, 7, 9 and 13
+    chunks of eight channels go through every entry and exit of them."""
+    x = _rand(2, cin, 16, 16, seed=450 + cin)
+    gn = (1.0 + 0.3 * _rand(2, cin, seed=451 + cin), 0.3 * _rand(2, cin, seed=452 + cin))
+    w3 = _rand(64, cin, 3, 3, seed=453 + cin, scale=(9 * cin) ** -0.5)
+    w1 = _rand(128, cin, 1, 1, seed=454 + cin, scale=cin ** -0.5)
+    b3, b1 = _rand(64, seed=455), _rand(128, seed=456)
+    _close(_run_wino(x, w3, 74, bias=b3, gn=gn, gn_silu=True), _conv_ref(x, w3, bias=b3, gn=gn, gn_silu=True), tol=KTOL,
+           what=f"winograd74 {cin} channels")
+    for cfg in (29, 30):
+        _close(_run_conv(x, w1, cfg, bias=b1, gn=gn, gn_silu=False), _conv_ref(x, w1, bias=b1, gn=gn, gn_silu=False),
+               what=f"bf16x3 pointwise cfg{cfg} {cin} channels")
 
 
 def test_conv1x1_pointwise_bf16x3_item_width_does_not_change_bits():

@@ -12,9 +12,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-enum Kind { FMA = 0, PKFMA, AND, PERM, MOV, PKADD, EXP, RCP, ADD, CVTPK, DSREAD64, NKINDS };
+enum Kind { FMA = 0, PKFMA, AND, PERM, MOV, PKADD, EXP, RCP, ADD, CVTPK, DSREAD64, DOT2, NKINDS };
 static const char* kNames[] = {"v_fma_f32", "v_pk_fma_f32", "v_and_b32", "v_perm_b32", "v_mov_b32", "v_pk_add_f32", "v_exp_f32",
-                               "v_rcp_f32", "v_add_f32", "v_cvt_pk_bf16_f32", "ds_read_b64"};
+                               "v_rcp_f32", "v_add_f32", "v_cvt_pk_bf16_f32", "ds_read_b64", "v_dot2_f32_bf16"};
 
 template <int KIND>
 __device__ __forceinline__ void four(float& x0, float& x1, float& x2, float& x3, f2& p0, f2& p1, f2& p2, f2& p3, unsigned laddr) {
@@ -38,6 +38,8 @@ __device__ __forceinline__ void four(float& x0, float& x1, float& x2, float& x3,
         asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
     else if constexpr (KIND == CVTPK)
         asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1\n v_cvt_pk_bf16_f32 %1, %1, %2\n v_cvt_pk_bf16_f32 %2, %2, %3\n v_cvt_pk_bf16_f32 %3, %3, %0\n" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+    else if constexpr (KIND == DOT2)
+        asm volatile("v_dot2_f32_bf16 %0, %1, %4, %0\n v_dot2_f32_bf16 %1, %2, %4, %1\n v_dot2_f32_bf16 %2, %3, %4, %2\n v_dot2_f32_bf16 %3, %0, %4, %3\n" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "s"(0x0000bf80u));
     else if constexpr (KIND == DSREAD64)
         asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:512\n ds_read_b64 %2, %4 offset:1024\n ds_read_b64 %3, %4 offset:1536\n s_waitcnt lgkmcnt(0)\n"
                      : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(laddr) : "memory");
@@ -66,6 +68,20 @@ __global__ void __launch_bounds__(1024) probe(int iters, float* out) {
     float r = x0 + x1 + x2 + x3 + p0.x + p1.y + p2.x + p3.y;
     for (int k = 0; k < 4; ++k) r += acc[k][0] + acc[k][7];
     out[blockIdx.x * 1024 + threadIdx.x] = r + lds[lane];
+}
+
+// x - bf16(x) by one v_dot2_f32_bf16: (hi, .) . (-1, 0) + x -- exact?  Compared with the subtraction in fp32
+__global__ void dot2_check(const float* x, unsigned* bad, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x0 = x[i], x1 = x[(i + 1) % n];
+    unsigned hp;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp) : "v"(x0), "v"(x1));
+    float r0, r1;
+    asm volatile("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r0) : "v"(hp), "s"(0x0000bf80u), "v"(x0));
+    asm volatile("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r1) : "v"(hp), "s"(0xbf800000u), "v"(x1));
+    const float e0 = x0 - __uint_as_float(hp << 16), e1 = x1 - __uint_as_float(hp & 0xffff0000u);
+    if (__float_as_uint(r0) != __float_as_uint(e0) || __float_as_uint(r1) != __float_as_uint(e1)) atomicAdd(bad, 1u);
 }
 
 template <int M, int V, int KIND>
@@ -110,5 +126,24 @@ int main() {
     row<EXP>(iters, d_out, t_m, ghz);
     row<RCP>(iters, d_out, t_m, ghz);
     row<DSREAD64>(iters, d_out, t_m, ghz);
+    row<DOT2>(iters, d_out, t_m, ghz);
+    {   // residual by dot2: bit-equal to the fp32 subtraction on 4M values of mixed magnitude?
+        const int n = 1 << 22;
+        float* hx = new float[n];
+        unsigned seed = 12345u;
+        for (int i = 0; i < n; ++i) {
+            seed = seed * 1664525u + 1013904223u;
+            const float u = (float)(seed >> 8) * (1.0f / 16777216.0f) - 0.5f;
+            seed = seed * 1664525u + 1013904223u;
+            const int e = (int)(seed >> 27) - 16;
+            hx[i] = ldexpf(u, e);
+        }
+        float* dx; unsigned* dbad; unsigned hbad = 0;
+        (void)hipMalloc(&dx, n * sizeof(float)); (void)hipMalloc(&dbad, 4);
+        (void)hipMemcpy(dx, hx, n * sizeof(float), hipMemcpyHostToDevice); (void)hipMemset(dbad, 0, 4);
+        hipLaunchKernelGGL(dot2_check, dim3(n / 256), dim3(256), 0, 0, dx, dbad, n);
+        (void)hipMemcpy(&hbad, dbad, 4, hipMemcpyDeviceToHost);
+        printf("x - bf16_rne(x) by v_dot2_f32_bf16 against the fp32 subtraction: %u of %d pairs differ\n", hbad, n);
+    }
     return 0;
 }
