@@ -506,6 +506,7 @@ static int winograd_cfg(const sisic_conv_args& a) {
         // such layer of the headline model (profiles/r03/conv_bench_bf16x3.txt), the same error against float64
         static const bool bf3_on = [] { const char* e = std::getenv("SISIC_WINO_BF16X3"); return !e || std::atoi(e) != 0; }();
         if (bf3_on && !a.upsample && a.Cout % 64 == 0 && Hout % 16 == 0 && Wout % 16 == 0 && a.c0 + a.c1 >= 16 &&
+            a.c0 + a.c1 <= 2048 &&                                      // (its LDS table of the image's GroupNorm operands)
             4.0 * a.Cout * Hout * Wout < 2147483648.0)
             return 74;
         if (wide_on && !a.upsample) return a.Cout > 64 ? 68 : 69;
