@@ -502,10 +502,12 @@ static int winograd_cfg(const sisic_conv_args& a) {
         // measured per layer (tools/conv_bench.py, profiles/r02/conv_bench_geometries.txt): the 128-channel form wins 8-12 % on
         // every Cout >= 128 layer, the 64-channel two-workgroups-per-CU form 1-10 % on every Cout <= 64 layer
         // fp32-equivalent products on the bf16 matrix pipe (conv_winograd_bf3.inc) unless SISIC_WINO_BF16X3=0: 64 channels x
-        // 16 x 16 pixels per workgroup, so only where those tiles are full; measured 1.36 - 1.43x the third f32 form on every
+        // 16 x 16 pixels per workgroup, so only where those tiles are (nearly) full; measured 1.36 - 1.43x the third f32 form on every
         // such layer of the headline model (profiles/r03/conv_bench_bf16x3.txt), the same error against float64
         static const bool bf3_on = [] { const char* e = std::getenv("SISIC_WINO_BF16X3"); return !e || std::atoi(e) != 0; }();
-        if (bf3_on && !a.upsample && a.Cout % 64 == 0 && Hout % 16 == 0 && Wout % 16 == 0 && a.c0 + a.c1 >= 16 &&
+        // (ragged planes too when at least three quarters of the 16x16-pixel tiles' area is inside: the classifier's 56 / 28 / 14)
+        const int th = (Hout + 15) / 16 * 16, tw = (Wout + 15) / 16 * 16;
+        if (bf3_on && !a.upsample && a.Cout % 64 == 0 && 4 * Hout * Wout >= 3 * th * tw && a.c0 + a.c1 >= 16 &&
             a.c0 + a.c1 <= 2048 &&                                      // (its LDS table of the image's GroupNorm operands)
             4.0 * a.Cout * Hout * Wout < 2147483648.0)
             return 74;
