@@ -507,7 +507,9 @@ static int winograd_cfg(const sisic_conv_args& a) {
         static const bool bf3_on = [] { const char* e = std::getenv("SISIC_WINO_BF16X3"); return !e || std::atoi(e) != 0; }();
         // (ragged planes too when at least three quarters of the 16x16-pixel tiles' area is inside: the classifier's 56 / 28 / 14)
         const int th = (Hout + 15) / 16 * 16, tw = (Wout + 15) / 16 * 16;
-        if (bf3_on && !a.upsample && a.Cout % 64 == 0 && 4 * Hout * Wout >= 3 * th * tw && a.c0 + a.c1 >= 16 &&
+        // (nearest-2x inputs as well: all 16 positions on the bf16 pipe beat the f32 form's 9 on every upsample layer of the
+        //  UNet -- 562 -> 512 us over the three, profiles/r03/conv_bench_bf16x3.txt)
+        if (bf3_on && a.Cout % 64 == 0 && 4 * Hout * Wout >= 3 * th * tw && a.c0 + a.c1 >= 16 &&
             a.c0 + a.c1 <= 2048 &&                                      // (its LDS table of the image's GroupNorm operands)
             4.0 * a.Cout * Hout * Wout < 2147483648.0)
             return 74;

@@ -946,7 +946,8 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.ksplit = 1;
     static const bool col_default = [] { const char* e = std::getenv("SISIC_WINO_COL"); return !e || std::atoi(e) != 0; }();
     if (cfg == 74) {                // fp32-equivalent products on the bf16 pipe (conv_winograd_bf3.inc)
-        SISIC_REQUIRE(!p.ups, "conv2d(winograd bf16x3): no upsample form");
+        // (a nearest-2x input is read through the staging plan's addresses: all 16 positions are multiplied, where the f32
+        //  upsample form multiplies 9 -- which of the two is faster depends on the plane, conv_mfma.hip)
         p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1);
         p.cout_pad = round_up(a.Cout, 128);
         return launch_bf3_pro(ctx, p, s);

@@ -209,7 +209,9 @@ def test_conv3x3_winograd(cfg, B, H, W):
 @pytest.mark.parametrize("cfg,H,W", [(60, 16, 16), (60, 8, 8), (60, 10, 14), (61, 4, 4), (62, 16, 16), (62, 10, 14),
                                      (63, 4, 4),
                                      # 66 / auto: the nine-position form for nearest-2x inputs
-                                     (66, 16, 16), (66, 8, 8), (66, 10, 14), (66, 5, 9), (66, 32, 32), (0, 8, 8), (0, 20, 12)])
+                                     (66, 16, 16), (66, 8, 8), (66, 10, 14), (66, 5, 9), (66, 32, 32), (0, 8, 8), (0, 20, 12),
+                                     # 74: the bf16x3 form reads a nearest-2x input through its staging addresses (all 16 positions)
+                                     (74, 16, 16), (74, 10, 14), (74, 32, 32), (0, 32, 32)])
 def test_conv3x3_winograd_upsample(cfg, H, W):
     x = _rand(2, 24, H, W, seed=120)
     w = _rand(64, 24, 3, 3, seed=121, scale=0.1)
