@@ -287,7 +287,7 @@ def main():
             tot_ns, calls = 0.0, 0
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    pat = (r"conv_winograd_bf3_kernel<\d>" if bf3 else
+                    pat = (r"conv_winograd_bf3_kernel<\d" if bf3 else
                            r"conv_winograd_(wide|col)_kernel<\d+, \d+, \d, false>|conv_winograd_kernel<1, 8, 8, \d, 16, false>")
                     if re.search(pat, row["Name"]):
                         tot_ns += float(row["TotalDurationNs"])
