@@ -491,7 +491,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
 // there are 32-bit).  Returns the tile configuration, 0 = not Winograd.
 static int winograd_cfg(const sisic_conv_args& a) {
     if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4) || a.upsample == 2) return 0;
-    if ((a.tile_cfg >= 60 && a.tile_cfg <= 74) || a.tile_cfg == 78 || a.tile_cfg == 79 || a.tile_cfg == 90 || a.tile_cfg == 91) return a.tile_cfg;
+    if ((a.tile_cfg >= 60 && a.tile_cfg <= 74) || a.tile_cfg == 78 || a.tile_cfg == 79 || (a.tile_cfg >= 90 && a.tile_cfg <= 92)) return a.tile_cfg;
     if (a.tile_cfg != 0) return 0;
     const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
     const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
@@ -524,6 +524,10 @@ static int winograd_cfg(const sisic_conv_args& a) {
     if (ksplit_on && Hout <= 8 && Wout <= 8 && Hout >= 5 && Wout >= 5 && Cin >= 128 && Cin % 32 == 0 && a.Cout >= 128) {
         // second geometry with two images per workgroup (tile_cfg 91): 45 -> 39 us and 67 -> 57 us per launch at B = 64
         static const bool wide_on = [] { const char* e = std::getenv("SISIC_WINO_WIDE"); return !e || std::atoi(e) != 0; }();
+        // tile_cfg 92: the same split with fp32-equivalent products on the bf16 pipe, four images per workgroup
+        // (conv_winograd_bf3.inc): 38 -> 32 and 59 -> 47 us per launch at B = 64 (profiles/r03/conv_bench_bf16x3.txt)
+        static const bool bf3_on = [] { const char* e = std::getenv("SISIC_WINO_BF16X3"); return !e || std::atoi(e) != 0; }();
+        if (bf3_on && !a.upsample && a.Cout % 64 == 0 && Cin <= 512) return 92;
         return (wide_on && !a.upsample) ? 91 : 90;
     }
     return 0;
@@ -536,7 +540,7 @@ static bool winograd_selected(const sisic_conv_args& a) { return winograd_cfg(a)
 // it would launch).  The vector-ALU small-Cout kernel does not produce them.
 int conv_stats_slots(const sisic_conv_args& a) {
     if (const int cfg = winograd_cfg(a)) {
-        if (cfg == 90 || cfg == 91) return 1;
+        if (cfg >= 90 && cfg <= 92) return 1;
         const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
         if ((cfg == 78 || cfg == 79) && wino_latency_ksplit(a.Cout, a.c0 + a.c1, Hout, Wout) > 1) return wino_latency_segments(Hout, Wout);   // from the plane reduction
         if ((cfg >= 68 && cfg <= 73) || cfg == 78 || cfg == 79) return ((Hout + 7) / 8) * ((Wout + 15) / 16);   // 8 x 16 output pixels per workgroup
@@ -606,7 +610,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         SISIC_REQUIRE(!slots_query, "conv2d: internal: slot query on the Winograd path");
         return launch_conv_winograd(ctx, a, a.w_winograd, winograd_cfg(a), s);
     }
-    SISIC_REQUIRE((cfg < 60 || cfg > 74) && cfg != 78 && cfg != 79 && cfg != 90 && cfg != 91, "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
+    SISIC_REQUIRE((cfg < 60 || cfg > 74) && cfg != 78 && cfg != 79 && (cfg < 90 || cfg > 92), "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 2>(ctx, p, s);   // 2-channel chunks: 4 spill 256 B/lane (13 weight float4 + 15 halo elements per thread)

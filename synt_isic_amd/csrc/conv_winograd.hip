@@ -990,7 +990,7 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         SISIC_HIP(hipGetLastError());
         return SISIC_OK;
     }
-    if (cfg == 90 || cfg == 91) {
+    if (cfg == 90 || cfg == 91 || cfg == 92) {
         constexpr int K = 4;
         const size_t HW = (size_t)p.Hc * p.Wc, planes = (size_t)a.B * a.Cout;
         SISIC_REQUIRE(HW <= 256 && (cdiv(a.c0 + a.c1, W_CIC) % K) == 0,
@@ -1012,7 +1012,12 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         }
         p.ksplit = K;
         p.part = scratch;
-        if (cfg == 91) {          // second geometry, two images per workgroup (conv_winograd_wide.inc, PAIR)
+        if (cfg == 92) {          // bf16x3 products, four images per workgroup (conv_winograd_bf3.inc)
+            SISIC_REQUIRE(!p.ups && p.Hc <= 8 && p.Wc <= 8, "conv2d(winograd bf16x3, 8x8): plain stride-1 convolutions of at most 8x8 pixels");
+            p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1);
+            p.cout_pad = round_up(a.Cout, 128);
+            SISIC_TRY(launch_bf3q_pro(ctx, p, s));
+        } else if (cfg == 91) {   // second geometry, two images per workgroup (conv_winograd_wide.inc, PAIR)
             SISIC_REQUIRE(!p.ups && p.Hc <= 8 && p.Wc <= 8, "conv2d(winograd wide, image pairs): plain stride-1 convolutions of at most 8x8 pixels");
             p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1);
             p.cout_pad = round_up(a.Cout, 128);

@@ -295,6 +295,36 @@ def test_conv3x3_winograd_ksplit_image_pairs(B, H, W, c0, c1, cout):
         _run_wino(_rand(2, 32, 8, 10, seed=298), _rand(64, 32, 3, 3, seed=299), 91)
 
 
+@pytest.mark.parametrize("B,H,W,c0,c1,cout", [(8, 8, 8, 64, 0, 64), (5, 8, 8, 40, 24, 70), (3, 6, 7, 96, 0, 128),
+                                              (32, 8, 8, 128, 0, 128), (1, 7, 7, 64, 0, 200), (6, 8, 8, 256, 256, 256)])
+def test_conv3x3_winograd_ksplit_bf16x3(B, H, W, c0, c1, cout):
+    """tile_cfg 92: the 8x8 level with fp32-equivalent products on the bf16 matrix pipe -- four images of <= 4x4 tiles per
+    workgroup, the input channels split four ways, the same reduction kernel as tile_cfg 90 / 91 (bias, embedding, residual,
+    ReLU, GroupNorm partials).  Same bound as the f32 forms; batches that are not a multiple of four leave images empty."""
+    x = _rand(B, c0, H, W, seed=390)
+    x2 = _rand(B, c1, H, W, seed=391) if c1 else None
+    w = _rand(cout, c0 + c1, 3, 3, seed=392, scale=(9 * (c0 + c1)) ** -0.5)
+    b = _rand(cout, seed=393)
+    gn = (1.0 + 0.3 * _rand(B, c0 + c1, seed=394), 0.3 * _rand(B, c0 + c1, seed=395))
+    cb = _rand(B, cout, seed=396)
+    res = _rand(B, cout, H, W, seed=397)
+    for kw in (dict(bias=b, x2=x2, gn=gn, gn_silu=True, chan_bias=cb, residual=res), dict(bias=b, x2=x2, relu=True),
+               dict(bias=b, x2=x2, gn=gn, gn_silu=False)):
+        _close(_run_wino(x, w, 92, **kw), _conv_ref(x, w, **kw), tol=KTOL, what="winograd bf16x3 K-split, four images")
+    from synt_isic_amd import ops
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 3, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=92,
+                       w_winograd=ops.pack_winograd_weight(d(w)), with_stats=True)
+    assert st is not None and tuple(st.shape) == (B, cout, 1, 4)
+    G = 2 if cout % 32 else 32
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=398), 0.1 * _rand(cout, seed=399)
+    sc, sh = ops.groupnorm_finalize(st, H * W, d(gamma), d(beta), G, 1e-5)
+    yc = y.cpu().double()
+    ref = F.group_norm(yc, G, gamma.double(), beta.double(), 1e-5)
+    got = yc * sc.cpu().double()[:, :, None, None] + sh.cpu().double()[:, :, None, None]
+    _close(got.float(), ref, tol=KTOL, what="groupnorm from the K-split reduction, bf16x3")
+
+
 def test_conv3x3_winograd_reference_layers_and_identity():
     # identity filter: the transform pair must reproduce the input up to fp32 rounding of the 1/2, 1/4 weights
     C = 64

@@ -25,6 +25,8 @@ cd $R
   timeout -k 10 300 python tools/conv_bench.py --cfgs 71,74 --match "@64 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
   timeout -k 10 300 python tools/conv_bench.py --cfgs 70,74 --match "@32 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
   timeout -k 10 300 python tools/conv_bench.py --cfgs 70,74 --match "@16 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
+  echo "# python tools/conv_bench.py --cfgs 91,92 --match '@8 gn': the 8x8 level, K-split f32 form (two images per workgroup) vs K-split bf16x3 form (four)"
+  timeout -k 10 300 python tools/conv_bench.py --cfgs 91,92 --match "@8 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
   echo "# python tools/conv_bench.py --cfgs 66,74 --match 'up ': the nearest-2x upsample convolutions, nine-position f32 form vs the bf16x3 form (16 positions)"
   timeout -k 10 300 python tools/conv_bench.py --cfgs 66,74 --match "up " --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
   echo "# python tools/conv_bench.py --cfgs 20,28 --match 1x1: the 1x1 layers, f32 pointwise kernel vs the bf16x3 pointwise kernel"
