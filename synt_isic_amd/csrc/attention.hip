@@ -7,9 +7,13 @@
 //
 // One wave owns 32 queries of one (sample, head); a workgroup (4 waves) owns 128 queries and
 // shares the head's K/V rows through LDS in blocks of 256 keys.
-//   * S^T = K^T Q on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32, 4 k-steps for d=8), computed
-//     "swapped" so the query sits on the lane and its keys in the 16 accumulator registers:
-//     the softmax row reduction is register-local plus one cross-half shuffle;
+//   * S^T = K^T Q with fp32-EQUIVALENT products on the bf16 matrix pipe (round 3; the arithmetic of conv_winograd_bf3.inc:
+//     q and k split exactly into three bf16 terms, six of the nine term products in three v_mfma_f32_32x32x16_bf16 --
+//     K = 16 is the eight head dimensions x two terms -- 96 matrix cycles per 32 x 32 score tile instead of the 256 of four
+//     v_mfma_f32_32x32x2_f32, and on a pipe of its own: the f32 MFMA IS the vector unit this kernel is bound by).  K is
+//     split once per key block while it is staged into LDS, q once per wave.  Computed "swapped" so the query sits on
+//     the lane and its keys in the 16 accumulator registers: the softmax row reduction is register-local plus one
+//     cross-half shuffle;
 //   * softmax in fp32, online (running max / sum / output) across 32-key tiles and key blocks;
 //   * P.V on the vector ALU: with d=8 the MFMA tile would be 3/4 padding (and fp32 MFMA is only twice the packed
 //     vector rate).  V sits in LDS as [key][d], so one key's eight values are two broadcast ds_read_b128 whose
@@ -24,6 +28,20 @@ namespace sisic {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short att_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned att_u2 __attribute__((ext_vector_type(2)));
+
+// x = hi + mid + lo exactly (8 + 8 + 8 significant bits); the terms of two values packed [b : a] per dword
+__device__ __forceinline__ void att_split2(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned ha = __float_as_uint(a) & 0xffff0000u, hb = __float_as_uint(b) & 0xffff0000u;
+    const float ra = a - __uint_as_float(ha), rb = b - __uint_as_float(hb);
+    const unsigned ma = __float_as_uint(ra) & 0xffff0000u, mb = __float_as_uint(rb) & 0xffff0000u;
+    const float la = ra - __uint_as_float(ma), lb = rb - __uint_as_float(mb);
+    hi = __builtin_amdgcn_perm(hb, ha, 0x07060302u);
+    mid = __builtin_amdgcn_perm(mb, ma, 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+}
 
 constexpr int ATT_D = 8;
 constexpr int ATT_KB = 256;       // keys per LDS block
@@ -33,7 +51,9 @@ constexpr int ATT_WAVES = 4;
 __global__ void __launch_bounds__(64 * ATT_WAVES)
 attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, int heads, int q_blocks,
                  float scale) {
-    __shared__ __attribute__((aligned(16))) float Ks[ATT_D * ATT_KB];
+    // K of the block, split: per dimension group g (d = 4 g .. 4 g + 3) and key the packed terms (hi, mid) [4 dwords] and lo [2]
+    __shared__ __attribute__((aligned(16))) unsigned Kh[2 * ATT_KB * 4];
+    __shared__ __attribute__((aligned(16))) unsigned Kl[2 * ATT_KB * 2];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_D * ATT_KB];
 
     int blk = blockIdx.x;
@@ -54,9 +74,19 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
 
     // the softmax scale AND log2(e) are folded into q once: the score tile needs no multiply and p = 2^(s - m) is a bare
     // v_exp_f32 (softmax is invariant under the common base change)
-    float qreg[4];
+    // lane = (query, dimension group g = half): the B operands of the three MFMAs, (q_hi, q_mid), (q_mid, q_hi), (q_lo, q_hi)
+    att_u4 b_hm, b_mh, b_lh;
+    {
+        float qv[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qreg[s] = (q < N) ? Qp[(size_t)(2 * s + half) * N + q] * scale : 0.0f;
+        for (int k = 0; k < 4; ++k) qv[k] = (q < N) ? Qp[(size_t)(4 * half + k) * N + q] * scale : 0.0f;
+        unsigned h0, m0, l0, h1, m1, l1;
+        att_split2(qv[0], qv[1], h0, m0, l0);
+        att_split2(qv[2], qv[3], h1, m1, l1);
+        b_hm = att_u4{h0, h1, m0, m1};
+        b_mh = att_u4{m0, m1, h0, h1};
+        b_lh = att_u4{l0, l1, h0, h1};
+    }
 
     float m_run = -INFINITY, l_part = 0.0f;
     f32x2 o2[ATT_D / 2];
@@ -73,10 +103,14 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float a = Ks[(2 * s + half) * ATT_KB + kt * 32 + l31];
-            S = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], S, 0, 0, 0);
+        {   // k_hi q_hi + k_mid q_mid, k_hi q_mid + k_mid q_hi, k_hi q_lo + k_lo q_hi
+            const int key = half * ATT_KB + kt * 32 + l31;
+            const att_u4 a_hm = *reinterpret_cast<const att_u4*>(&Kh[key * 4]);
+            const att_u2 a_l = *reinterpret_cast<const att_u2*>(&Kl[key * 2]);
+            const att_u4 a_hl = {a_hm.x, a_hm.y, a_l.x, a_l.y};
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hm), __builtin_bit_cast(att_bf16x8, b_hm), S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hm), __builtin_bit_cast(att_bf16x8, b_mh), S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hl), __builtin_bit_cast(att_bf16x8, b_lh), S, 0, 0, 0);
         }
         float tmax = -INFINITY;
 #pragma unroll
@@ -116,10 +150,17 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
 
     for (int kb0 = 0; kb0 < N; kb0 += ATT_KB) {
         __syncthreads();
-        for (int idx = tid; idx < ATT_D * ATT_KB; idx += 64 * ATT_WAVES) {     // K: [d][key]
-            const int d = idx / ATT_KB, k = idx % ATT_KB;
+        for (int idx = tid; idx < 2 * ATT_KB; idx += 64 * ATT_WAVES) {         // K: (dimension group, key) -> its split terms
+            const int g = idx / ATT_KB, k = idx % ATT_KB;
             const int key = kb0 + k;
-            Ks[idx] = key < N ? Kp[(size_t)d * N + key] : 0.0f;
+            float kv[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) kv[d] = key < N ? Kp[(size_t)(4 * g + d) * N + key] : 0.0f;
+            unsigned h0, m0, l0, h1, m1, l1;
+            att_split2(kv[0], kv[1], h0, m0, l0);
+            att_split2(kv[2], kv[3], h1, m1, l1);
+            *reinterpret_cast<att_u4*>(&Kh[idx * 4]) = att_u4{h0, h1, m0, m1};
+            *reinterpret_cast<att_u2*>(&Kl[idx * 2]) = att_u2{l0, l1};
         }
         for (int k = tid; k < ATT_KB; k += 64 * ATT_WAVES) {                   // V: [key][d], one key per thread
             const int key = kb0 + k;
