@@ -132,6 +132,8 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
     };
     pwb_u4 ua[CB];               // (U_hi, U_mid) of the current chunk
     pwb_u2 ul[CB];               // U_lo
+    pwb_u4 ub[CB];               // 32-pixel form only: the filters of the chunk after (a second set: requested a whole chunk
+    pwb_u2 um[CB];               // before their use -- with one set the L2 latency of every chunk's filters was in the open)
     // activations: one chunk ahead in registers (two sets); filters: requested as soon as the previous chunk's MFMAs are
     // issued -- the SIMD's other waves cover that latency, there is no barrier to hold them back
     auto load_x = [&](int c, XRegs& r) {
@@ -154,6 +156,14 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
         for (int x = 0; x < CB; ++x) {
             ua[x] = __builtin_amdgcn_raw_buffer_load_b128(rsw, a_lane16, s0 + 1024u * (unsigned)x, 0);
             ul[x] = __builtin_amdgcn_raw_buffer_load_b64(rsw, a_lane8, s0 + 2048u + 512u * (unsigned)x, 0);
+        }
+    };
+    auto load_b = [&](int c) {
+        const unsigned s0 = 3072u * (unsigned)(c * p.n_co64 + co_i);
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+            ub[x] = __builtin_amdgcn_raw_buffer_load_b128(rsw, a_lane16, s0 + 1024u * (unsigned)x, 0);
+            um[x] = __builtin_amdgcn_raw_buffer_load_b64(rsw, a_lane8, s0 + 2048u + 512u * (unsigned)x, 0);
         }
     };
     struct Tup { pwb_u4 hm, mh, lh; };                           // the three B operands of a 32-pixel block
@@ -192,16 +202,17 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
         }
         return Tup{pwb_u4{hi[0], hi[1], mid[0], mid[1]}, pwb_u4{mid[0], mid[1], hi[0], hi[1]}, pwb_u4{lo[0], lo[1], hi[0], hi[1]}};
     };
-    auto mm = [&](const Tup& t, auto nb_tag) {
+    auto mm_with = [&](const Tup& t, auto nb_tag, const pwb_u4 (&fa)[CB], const pwb_u2 (&fl)[CB]) {
         constexpr int nb = decltype(nb_tag)::value;
 #pragma unroll
         for (int x = 0; x < CB; ++x) {
-            const pwb_u4 a_hl = {ua[x].x, ua[x].y, ul[x].x, ul[x].y};
-            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, ua[x]), __builtin_bit_cast(pwb_bf16x8, t.hm), acc[x][nb], 0, 0, 0);
-            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, ua[x]), __builtin_bit_cast(pwb_bf16x8, t.mh), acc[x][nb], 0, 0, 0);
+            const pwb_u4 a_hl = {fa[x].x, fa[x].y, fl[x].x, fl[x].y};
+            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, fa[x]), __builtin_bit_cast(pwb_bf16x8, t.hm), acc[x][nb], 0, 0, 0);
+            acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, fa[x]), __builtin_bit_cast(pwb_bf16x8, t.mh), acc[x][nb], 0, 0, 0);
             acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, a_hl), __builtin_bit_cast(pwb_bf16x8, t.lh), acc[x][nb], 0, 0, 0);
         }
     };
+    auto mm = [&](const Tup& t, auto nb_tag) { mm_with(t, nb_tag, ua, ul); };
     using Z = std::integral_constant<int, 0>;
     using O = std::integral_constant<int, 1>;
 
@@ -233,28 +244,27 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
                 __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);       // eight vector instructions
             }
         };
-        if (n > 1) load_x(1, rb);
+        if (n > 1) { load_x(1, rb); load_b(1); }
         Tup t = make(0, ra, 0);
         int c = 0;
-        for (; c + 2 < n; c += 2) {
+        for (; c + 2 < n; c += 2) {             // t: operands of chunk c (even); filters: even chunks in (ua, ul), odd in (ub, um)
             load_x(c + 2, ra);
             Tup u = make(c + 1, rb, 0);
-            mm(t, Z{});
-            weave();
-            load_a(c + 1);
-            if (c + 3 < n) load_x(c + 3, rb);
-            t = make(c + 2, ra, 0);
-            mm(u, Z{});
+            mm_with(t, Z{}, ua, ul);
             weave();
             load_a(c + 2);
+            if (c + 3 < n) load_x(c + 3, rb);
+            t = make(c + 2, ra, 0);
+            mm_with(u, Z{}, ub, um);
+            weave();
+            if (c + 3 < n) load_b(c + 3);
         }
         if (c + 1 < n) {
             Tup u = make(c + 1, rb, 0);
-            mm(t, Z{});
-            load_a(c + 1);
-            mm(u, Z{});
+            mm_with(t, Z{}, ua, ul);
+            mm_with(u, Z{}, ub, um);
         } else {
-            mm(t, Z{});
+            mm_with(t, Z{}, ua, ul);
         }
     }
 
