@@ -259,6 +259,47 @@ def test_conv3x3_winograd_ksplit(B, H, W, c0, c1, cout):
         _run_wino(x[:, :24].contiguous(), w[:, :24].contiguous(), 90)        # 3 chunks do not split four ways
 
 
+@pytest.mark.parametrize("B,H,W,c0,c1,cout,ups", [
+    (20, 64, 64, 16, 0, 64, False),       # 320 items on 256 persistent workgroups: a quarter of them take a second item
+    (70, 28, 28, 24, 8, 64, False),       # 280 items, ragged planes, two sources: padding slots differ from item to item
+    (9, 32, 32, 16, 0, 128, True),        # nearest-2x input: 9 x 16 x 2 = 288 items
+    (33, 16, 16, 32, 0, 512, False),      # 264 items that differ in their channel tile only
+    (40, 64, 64, 16, 0, 64, False),       # 640 items: two or three per workgroup
+])
+def test_conv3x3_winograd_bf16x3_persistent_workgroups(B, H, W, c0, c1, cout, ups):
+    """More work items than CUs: a workgroup of the bf16x3 Winograd kernel takes several, requesting the next item's first
+    halo chunks before its output rounds.  Every feature of the epilogue and the GroupNorm partials, against float64; and
+    every image equal, bit for bit, to the same image convolved in a batch that gives each workgroup one item."""
+    from synt_isic_amd import ops
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    x = _rand(B, c0, H, W, seed=800)
+    x2 = _rand(B, c1, H, W, seed=801) if c1 else None
+    C = c0 + c1
+    w = _rand(cout, C, 3, 3, seed=802, scale=0.1)
+    b = _rand(cout, seed=803)
+    gn = None if ups else (1.0 + 0.3 * _rand(B, C, seed=804), 0.3 * _rand(B, C, seed=805))
+    cb = _rand(B, cout, seed=806)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    res = _rand(B, cout, Ho, Wo, seed=807)
+    wp, ww = ops.pack_conv_weight(d(w)), ops.pack_winograd_weight(d(w))
+
+    def run(sl):
+        return ops.conv2d(d(x[sl]), wp, cout, 3, bias=d(b), x2=d(x2[sl]) if c1 else None, upsample=ups,
+                          gn_scale=d(gn[0][sl]) if gn else None, gn_shift=d(gn[1][sl]) if gn else None, gn_silu=bool(gn),
+                          chan_bias=d(cb[sl]), residual=d(res[sl]), tile_cfg=74, w_winograd=ww, with_stats=True)
+    y, st = run(slice(0, B))
+    ref = _conv_ref(x, w, bias=b, x2=x2, upsample=ups, gn=gn, gn_silu=bool(gn), chan_bias=cb, residual=res)
+    _close(y, ref, tol=KTOL, what="bf16x3 winograd, several items per workgroup")
+    # images from both ends and the middle, alone (a handful of items: one per workgroup)
+    for i in (0, B // 2, B - 1):
+        yi, sti = run(slice(i, i + 1))
+        assert torch.equal(yi[0], y[i]) and torch.equal(sti[0], st[i]), f"image {i} differs from the same image alone"
+    n = st[..., 0].sum(dim=2)
+    assert torch.all(n == Ho * Wo)
+    mean = (st[..., 1].double().sum(dim=2) / (Ho * Wo)).cpu()
+    _close(mean.float(), ref.mean(dim=(2, 3)), tol=KTOL, what="partials' sums, several items per workgroup")
+
+
 @pytest.mark.parametrize("B,H,W,c0,c1,cout", [(8, 8, 8, 64, 0, 64), (5, 8, 8, 40, 24, 70), (3, 6, 7, 96, 0, 128),
                                               (32, 8, 8, 128, 0, 128), (1, 7, 7, 64, 0, 200), (2, 4, 4, 32, 0, 256)])
 def test_conv3x3_winograd_ksplit_image_pairs(B, H, W, c0, c1, cout):
