@@ -61,7 +61,7 @@ def run(cin, cout, hw, B, res=True, clock_ghz=0.1):
     # the launch: its workgroups run back to back on their CU, so (workgroups per CU) x (median life) is about the event time
     life_ticks = (t[:, :, 15].max(dim=1).values - t[:, :, 0].min(dim=1).values)
     ev_us = e0.elapsed_time(e1) * 1e3
-    span_ticks = life_ticks.median().item() * max(nwg / 256.0, 1.0)
+    span_ticks = (t[:, :, 15].max().item() - t[:, :, 0].min().item()) if False else life_ticks.median().item() * max(nwg / 256.0, 1.0)
     tick_us = ev_us / span_ticks
     print(f"=== {cin}->{cout} @{hw}x{hw} B={B}: {nwg} workgroups, event time {ev_us:.1f} us ~ {span_ticks:.0f} ticks "
           f"({1 / tick_us:.1f} ticks / us)")
@@ -77,6 +77,16 @@ def run(cin, cout, hw, B, res=True, clock_ghz=0.1):
         print(f"      {NAMES[k]:26s} {f:7.2f} {m:7.2f} {l:7.2f}{d}")
         prev = m
     life = (t[:, :, 15].max(dim=1).values - t[:, :, 0].min(dim=1).values) * tick_us
+    grid = min(nwg, 256)
+    if nwg > grid and os.environ.get("SISIC_BF3_PERSISTENT", "1") != "0":
+        # persistent workgroups: item L + grid follows item L on the same workgroup (same clock)
+        first = life[:grid].median().item()
+        later = life[grid:].median().item()
+        gap = ((t[grid:, :, 0].min(dim=1).values - t[: nwg - grid, :, 15].max(dim=1).values) * tick_us).median().item()
+        pro_first = rel[:grid, :, 1].median(dim=1).values.median().item()
+        pro_later = rel[grid:, :, 1].median(dim=1).values.median().item()
+        print(f"    persistent: first item {first:.2f} us (prologue {pro_first:.2f}), later items {later:.2f} us (prologue {pro_later:.2f}), "
+              f"last wave's end -> first wave's next start {gap:.2f} us")
     print(f"    workgroup life: median {life.median():.2f} us; {nwg / 256:.1f} workgroups per CU -> {life.median() * nwg / 256:.1f} us if back to back")
 
 

@@ -3,7 +3,7 @@
 set -e
 timeout -k 10 500 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "winograd or tail" 2>&1 | tail -3
 for rep in 1 2; do
-for v in shipped persist persist2; do
+for v in shipped persist2 persist3; do
   export SISIC_LIB_PATH=$PWD/tools/bin/libsisic_$v.so
   echo "== $v"
   timeout -k 10 300 python tools/conv_bench.py --cfgs 74 --iters 30 --match "@64 gn" 2>&1 | grep -v "^sum\|amdgpu.ids\|best cfg\|probe"
