@@ -267,6 +267,7 @@ def test_conv3x3_winograd_ksplit(B, H, W, c0, c1, cout):
     (40, 64, 64, 16, 0, 64, False),       # 640 items: two or three per workgroup
     (65, 32, 32, 16, 0, 64, False),       # 260 items, not a multiple of 8: the work remap is irregular, every item is decoded
     (32, 48, 48, 16, 0, 64, False),       # 288 items of 9 positions per image: a workgroup's next item is another position (new plan)
+    (30, 40, 40, 16, 8, 64, False),       # 270 items, ragged 40 = 2.5 tiles: the next item is another position with OTHER padding slots
 ])
 def test_conv3x3_winograd_bf16x3_persistent_workgroups(B, H, W, c0, c1, cout, ups):
     """More work items than CUs: a workgroup of the bf16x3 Winograd kernel takes several, requesting the next item's first
