@@ -121,7 +121,10 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
             }
             tmax = fmaxf(tmax, S[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        {   // the other half's maximum: v_permlane32_swap (one instruction; __shfl_xor is an LDS round trip)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first tile: 2^(-inf) = 0; unchanged maximum: 1
         l_part *= alpha;
@@ -131,8 +134,12 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             float pv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pv[i] = __builtin_amdgcn_exp2f(S[4 * rq + i] - m_new);   // masked keys: 2^(-inf) = 0
+            {   // (two subtractions per instruction: v_pk_add_f32 with the maximum negated -- this loop is bound by its vector instructions)
+                const f32x2 mm = f32x2{m_new, m_new};
+                const f32x2 d0 = f32x2{S[4 * rq], S[4 * rq + 1]} - mm, d1 = f32x2{S[4 * rq + 2], S[4 * rq + 3]} - mm;
+                pv[0] = __builtin_amdgcn_exp2f(d0.x); pv[1] = __builtin_amdgcn_exp2f(d0.y);           // masked keys: 2^(-inf) = 0
+                pv[2] = __builtin_amdgcn_exp2f(d1.x); pv[3] = __builtin_amdgcn_exp2f(d1.y);
+            }
             l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
             const int koff = kt * 32 + 8 * rq + 4 * half;
 #pragma unroll
