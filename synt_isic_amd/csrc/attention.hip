@@ -5,8 +5,8 @@
 // projections are 1x1 convolutions (conv_mfma.hip) that leave q,k,v as [B, 3C, N] with the
 // token index contiguous, so every operand here is read as contiguous rows.
 //
-// One wave owns 32 queries of one (sample, head); a workgroup (4 waves) owns 128 queries and
-// shares the head's K/V rows through LDS in blocks of 256 keys.
+// One wave owns 32 or 64 queries of one (sample, head) (attention_kernel<QB>); a workgroup (4 waves) owns 128 or 256
+// queries and shares the head's K/V rows through LDS in blocks of 256 keys.
 //   * S^T = K^T Q with fp32-EQUIVALENT products on the bf16 matrix pipe (round 3; the arithmetic of conv_winograd_bf3.inc:
 //     q and k split exactly into three bf16 terms, six of the nine term products in three v_mfma_f32_32x32x16_bf16 --
 //     K = 16 is the eight head dimensions x two terms -- 96 matrix cycles per 32 x 32 score tile instead of the 256 of four
@@ -20,6 +20,7 @@
 //     register pairs feed v_pk_fma_f32 directly: four packed FMAs per (query, key), no operand shuffling.
 //
 // Algorithmic bytes per launch: 4*B*4*C*N (q,k,v in, o out).  FLOPs: 4*B*C*N*N.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -48,6 +49,10 @@ constexpr int ATT_KB = 256;       // keys per LDS block
 constexpr int ATT_KT = ATT_KB / 32;
 constexpr int ATT_WAVES = 4;
 
+// QB: 32-query blocks per wave.  With two, a key's K operands and its eight V values -- two broadcast ds_read_b128, the LDS
+// traffic this loop is bound by -- are read once for 64 queries, and a workgroup stages the head's K / V once for 256 queries.
+// A query's arithmetic does not depend on QB (same keys, same order, same operations): the choice may follow the batch.
+template <int QB>
 __global__ void __launch_bounds__(64 * ATT_WAVES)
 attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, int heads, int q_blocks,
                  float scale) {
@@ -64,8 +69,7 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int q0 = qb * (32 * ATT_WAVES) + wave * 32;
-    const int q = q0 + l31;
+    const int q0 = qb * (32 * QB * ATT_WAVES) + wave * (32 * QB);     // the wave's queries: q0 + 32 j + l31
     const bool wave_active = q0 < N;      // wave-uniform
 
     const float* Qp = qkv + ((size_t)b * 3 * C + (size_t)head * ATT_D) * N;
@@ -75,23 +79,29 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
     // the softmax scale AND log2(e) are folded into q once: the score tile needs no multiply and p = 2^(s - m) is a bare
     // v_exp_f32 (softmax is invariant under the common base change)
     // lane = (query, dimension group g = half): the B operands of the three MFMAs, (q_hi, q_mid), (q_mid, q_hi), (q_lo, q_hi)
-    att_u4 b_hm, b_mh, b_lh;
-    {
+    att_u4 b_hm[QB], b_mh[QB], b_lh[QB];
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const int q = q0 + 32 * j + l31;
         float qv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) qv[k] = (q < N) ? Qp[(size_t)(4 * half + k) * N + q] * scale : 0.0f;
         unsigned h0, m0, l0, h1, m1, l1;
         att_split2(qv[0], qv[1], h0, m0, l0);
         att_split2(qv[2], qv[3], h1, m1, l1);
-        b_hm = att_u4{h0, h1, m0, m1};
-        b_mh = att_u4{m0, m1, h0, h1};
-        b_lh = att_u4{l0, l1, h0, h1};
+        b_hm[j] = att_u4{h0, h1, m0, m1};
+        b_mh[j] = att_u4{m0, m1, h0, h1};
+        b_lh[j] = att_u4{l0, l1, h0, h1};
     }
 
-    float m_run = -INFINITY, l_part = 0.0f;
-    f32x2 o2[ATT_D / 2];
+    float m_run[QB], l_part[QB];
+    f32x2 o2[QB][ATT_D / 2];
 #pragma unroll
-    for (int d = 0; d < ATT_D / 2; ++d) o2[d] = f32x2{0.0f, 0.0f};
+    for (int j = 0; j < QB; ++j) {
+        m_run[j] = -INFINITY; l_part[j] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < ATT_D / 2; ++d) o2[j][d] = f32x2{0.0f, 0.0f};
+    }
 
     // One pass per 32-key tile with an online softmax (running maximum m_run, running sum l_part, running
     // output o2[]): S^T tile on the MFMA pipe, tile maximum, rescale of the running state when the maximum
@@ -100,57 +110,74 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
     // MASKED: the tile reaches past the last key (only the final tile of a sequence that is no multiple of 32).
     auto tile = [&](const int kt, const int nk, auto masked) {
         constexpr bool MASKED = decltype(masked)::value;
-        f32x16 S;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+        f32x16 S[QB];
         {   // k_hi q_hi + k_mid q_mid, k_hi q_mid + k_mid q_hi, k_hi q_lo + k_lo q_hi
             const int key = half * ATT_KB + kt * 32 + l31;
             const att_u4 a_hm = *reinterpret_cast<const att_u4*>(&Kh[key * 4]);
             const att_u2 a_l = *reinterpret_cast<const att_u2*>(&Kl[key * 2]);
             const att_u4 a_hl = {a_hm.x, a_hm.y, a_l.x, a_l.y};
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hm), __builtin_bit_cast(att_bf16x8, b_hm), S, 0, 0, 0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hm), __builtin_bit_cast(att_bf16x8, b_mh), S, 0, 0, 0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hl), __builtin_bit_cast(att_bf16x8, b_lh), S, 0, 0, 0);
-        }
-        float tmax = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (MASKED) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                S[r] = (key < nk) ? S[r] : -INFINITY;
+            for (int j = 0; j < QB; ++j) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[j][r] = 0.0f;
+                S[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hm), __builtin_bit_cast(att_bf16x8, b_hm[j]), S[j], 0, 0, 0);
+                S[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hm), __builtin_bit_cast(att_bf16x8, b_mh[j]), S[j], 0, 0, 0);
+                S[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_hl), __builtin_bit_cast(att_bf16x8, b_lh[j]), S[j], 0, 0, 0);
             }
-            tmax = fmaxf(tmax, S[r]);
         }
-        {   // the other half's maximum: v_permlane32_swap (one instruction; __shfl_xor is an LDS round trip)
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-            tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // first tile: 2^(-inf) = 0; unchanged maximum: 1
-        l_part *= alpha;
+        float m_new[QB];
 #pragma unroll
-        for (int d = 0; d < ATT_D / 2; ++d) o2[d] *= alpha;
-        m_run = m_new;
+        for (int j = 0; j < QB; ++j) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (MASKED) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    S[j][r] = (key < nk) ? S[j][r] : -INFINITY;
+                }
+                tmax = fmaxf(tmax, S[j][r]);
+            }
+            {   // the other half's maximum: v_permlane32_swap (one instruction; __shfl_xor is an LDS round trip)
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                tmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            m_new[j] = fmaxf(m_run[j], tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new[j]);     // first tile: 2^(-inf) = 0; unchanged maximum: 1
+            // (multiplications the compiler cannot fuse with the additions that follow: fused -- l * alpha + sum, o * alpha + p v --
+            //  by one instantiation and not by the other, the two forms' bits would differ)
+            // (s_nop: alpha comes from v_exp_f32, and the hazard recognizer does not look inside an asm -- a vector instruction
+            //  that reads a transcendental's result in the next slot reads the old register; found as garbage in the masked tile)
+            asm("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(l_part[j]) : "v"(l_part[j]), "v"(alpha));
+            const f32x2 a2 = f32x2{alpha, alpha};
+#pragma unroll
+            for (int d = 0; d < ATT_D / 2; ++d) asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(o2[j][d]) : "v"(o2[j][d]), "v"(a2));
+            m_run[j] = m_new[j];
+        }
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            float pv[4];
-            {   // (two subtractions per instruction: v_pk_add_f32 with the maximum negated -- this loop is bound by its vector instructions)
-                const f32x2 mm = f32x2{m_new, m_new};
-                const f32x2 d0 = f32x2{S[4 * rq], S[4 * rq + 1]} - mm, d1 = f32x2{S[4 * rq + 2], S[4 * rq + 3]} - mm;
-                pv[0] = __builtin_amdgcn_exp2f(d0.x); pv[1] = __builtin_amdgcn_exp2f(d0.y);           // masked keys: 2^(-inf) = 0
-                pv[2] = __builtin_amdgcn_exp2f(d1.x); pv[3] = __builtin_amdgcn_exp2f(d1.y);
+            float pv[QB][4];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) {
+                // (two subtractions per instruction: v_pk_add_f32 with the maximum negated -- this loop is bound by its vector instructions)
+                const f32x2 mm = f32x2{m_new[j], m_new[j]};
+                const f32x2 d0 = f32x2{S[j][4 * rq], S[j][4 * rq + 1]} - mm, d1 = f32x2{S[j][4 * rq + 2], S[j][4 * rq + 3]} - mm;
+                pv[j][0] = __builtin_amdgcn_exp2f(d0.x); pv[j][1] = __builtin_amdgcn_exp2f(d0.y);           // masked keys: 2^(-inf) = 0
+                pv[j][2] = __builtin_amdgcn_exp2f(d1.x); pv[j][3] = __builtin_amdgcn_exp2f(d1.y);
+                l_part[j] += (pv[j][0] + pv[j][1]) + (pv[j][2] + pv[j][3]);
             }
-            l_part += (pv[0] + pv[1]) + (pv[2] + pv[3]);
             const int koff = kt * 32 + 8 * rq + 4 * half;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float4 va = *reinterpret_cast<const float4*>(&Vs[(koff + i) * ATT_D]);
                 const float4 vb = *reinterpret_cast<const float4*>(&Vs[(koff + i) * ATT_D + 4]);
-                const f32x2 p2 = f32x2{pv[i], pv[i]};
-                o2[0] += p2 * f32x2{va.x, va.y};
-                o2[1] += p2 * f32x2{va.z, va.w};
-                o2[2] += p2 * f32x2{vb.x, vb.y};
-                o2[3] += p2 * f32x2{vb.z, vb.w};
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    const f32x2 p2 = f32x2{pv[j][i], pv[j][i]};
+                    o2[j][0] += p2 * f32x2{va.x, va.y};
+                    o2[j][1] += p2 * f32x2{va.z, va.w};
+                    o2[j][2] += p2 * f32x2{vb.x, vb.y};
+                    o2[j][3] += p2 * f32x2{vb.z, vb.w};
+                }
             }
         }
     };
@@ -187,24 +214,27 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
         }
     }
 
-    float o[ATT_D];
-#pragma unroll
-    for (int d = 0; d < ATT_D / 2; ++d) { o[2 * d] = o2[d].x; o[2 * d + 1] = o2[d].y; }
-
     if (wave_active) {
-        const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
-        const float inv = 1.0f / l_tot;
-        float res[ATT_D];
 #pragma unroll
-        for (int d = 0; d < ATT_D; ++d) res[d] = (o[d] + __shfl_xor(o[d], 32, 64)) * inv;
-        if (q < N) {
-            float* Op = out + ((size_t)b * C + (size_t)head * ATT_D) * N + q;
+        for (int j = 0; j < QB; ++j) {
+            const int q = q0 + 32 * j + l31;
+            float o[ATT_D];
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                // bitwise select: a plain ?: on the array makes hipcc index it through scratch memory
-                const int hm = -half;
-                const float v = __int_as_float((__float_as_int(res[dd]) & ~hm) | (__float_as_int(res[4 + dd]) & hm));
-                Op[(size_t)(4 * half + dd) * N] = v;
+            for (int d = 0; d < ATT_D / 2; ++d) { o[2 * d] = o2[j][d].x; o[2 * d + 1] = o2[j][d].y; }
+            const float l_tot = l_part[j] + __shfl_xor(l_part[j], 32, 64);
+            const float inv = 1.0f / l_tot;
+            float res[ATT_D];
+#pragma unroll
+            for (int d = 0; d < ATT_D; ++d) res[d] = (o[d] + __shfl_xor(o[d], 32, 64)) * inv;
+            if (q < N) {
+                float* Op = out + ((size_t)b * C + (size_t)head * ATT_D) * N + q;
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    // bitwise select: a plain ?: on the array makes hipcc index it through scratch memory
+                    const int hm = -half;
+                    const float v = __int_as_float((__float_as_int(res[dd]) & ~hm) | (__float_as_int(res[4 + dd]) & hm));
+                    Op[(size_t)(4 * half + dd) * N] = v;
+                }
             }
         }
     }
@@ -215,13 +245,19 @@ int launch_attention(sisic_ctx* ctx, const float* qkv, float* out, int B, int C,
     SISIC_REQUIRE(head_dim == ATT_D, "attention: head_dim %d unsupported (the reference uses 8)", head_dim);
     SISIC_REQUIRE(B > 0 && N > 0 && C > 0 && C % head_dim == 0, "attention: bad shape B=%d C=%d N=%d", B, C, N);
     const int heads = C / head_dim;
-    const int q_blocks = cdiv(N, 32 * ATT_WAVES);
+    // two query blocks per wave where that still leaves every CU four workgroups (SISIC_ATT_QB=1|2 forces one form: same bits)
+    static const int qb_env = [] { const char* e = std::getenv("SISIC_ATT_QB"); return e ? std::atoi(e) : 0; }();
+    const int cus = ctx->num_cus > 0 ? ctx->num_cus : 256;
+    const int qb = qb_env == 1 || qb_env == 2 ? qb_env : ((int64_t)B * heads * cdiv(N, 64 * ATT_WAVES) >= 4 * (int64_t)cus ? 2 : 1);
+    const int q_blocks = cdiv(N, 32 * qb * ATT_WAVES);
     const int64_t grid = (int64_t)B * heads * q_blocks;
     SISIC_REQUIRE(grid < (int64_t(1) << 31), "attention: grid too large");
     ProfileScope prof(ctx, s, PK_ATTN, 16.0 * B * C * N, 4.0 * B * C * double(N) * N);
     const float scale = 1.4426950408889634f / sqrtf((float)head_dim);     // head_dim^-1/2 * log2(e)
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads,
-                       q_blocks, scale);
+    if (qb == 2)
+        hipLaunchKernelGGL(attention_kernel<2>, dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
+    else
+        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

@@ -747,6 +747,23 @@ def test_attention(N):
     _close(got, _attn_ref(qkv, C // 8), tol=KTOL, what=f"attention N={N}")
 
 
+@pytest.mark.parametrize("B,N", [(64, 64), (40, 256), (48, 100), (36, 300), (32, 1024), (33, 513)])
+def test_attention_two_query_blocks_per_wave(B, N):
+    """Large batches take attention_kernel<2> (64 queries per wave: a key's K operands and V values are read from LDS once
+    for two query blocks).  Against float64, and every image equal bit for bit to the same image in a batch of two, which
+    takes attention_kernel<1>: the form follows the batch, the bits must not."""
+    from synt_isic_amd import ops
+    C = 256
+    assert B * (C // 8) * ((N + 255) // 256) >= 4 * 256, "the case must select the two-block form (launch_attention)"
+    qkv = _rand(B, 3 * C, N, seed=940 + N) * 1.5
+    got = ops.attention(qkv.to(DEV), 8)
+    ref_idx = [0, B // 2, B - 1]
+    _close(got[ref_idx], _attn_ref(qkv[ref_idx], C // 8), tol=KTOL, what=f"attention, two query blocks per wave, N={N}")
+    for i in (0, B - 2):
+        small = ops.attention(qkv[i:i + 2].to(DEV).contiguous(), 8)
+        assert torch.equal(small, got[i:i + 2]), f"images {i}, {i + 1}: the two forms differ"
+
+
 def test_attention_online_rescale_branch():
     """N > 256 runs the online softmax across key blocks; spike a key in the LAST block so the running
     maximum jumps there and everything accumulated before must be rescaled (and the reverse)."""
