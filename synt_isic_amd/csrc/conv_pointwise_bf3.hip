@@ -137,6 +137,9 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
     // activations: one chunk ahead in registers (two sets); filters: requested as soon as the previous chunk's MFMAs are
     // issued -- the SIMD's other waves cover that latency, there is no barrier to hold them back
     auto load_x = [&](int c, XRegs& r) {
+#ifdef PWB_DIAG_NO_X_LOADS
+        if (c > 1) return;          // diagnostic: results wrong
+#endif
         const int cc0 = 8 * c;
         if (cc0 < p.c0) {                                           // the concat seam lies on a chunk boundary (launcher); a
             const unsigned soff = 4u * (unsigned)(cc0 * HW);        // uniform branch, not a select of the resource (waterfall)
@@ -151,6 +154,9 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
         }
     };
     auto load_a = [&](int c) {
+#ifdef PWB_DIAG_NO_FILTER_LOADS
+        if (c > 1) return;          // diagnostic: results wrong
+#endif
         const unsigned s0 = 3072u * (unsigned)(c * p.n_co64 + co_i);
 #pragma unroll
         for (int x = 0; x < CB; ++x) {
@@ -159,6 +165,9 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
         }
     };
     auto load_b = [&](int c) {
+#ifdef PWB_DIAG_NO_FILTER_LOADS
+        if (c > 1) return;
+#endif
         const unsigned s0 = 3072u * (unsigned)(c * p.n_co64 + co_i);
 #pragma unroll
         for (int x = 0; x < CB; ++x) {
