@@ -456,7 +456,7 @@ int launch_col_sums(sisic_ctx*, const float* m, int rows, int cols, int ld, floa
 // the order of plane_sum_kernel), lane 0 of each wave leaves S[b] in LDS; then S[b] goes to the time-embedding gradient
 // (column tproj_col + c of a [B, tproj_ld] matrix) when the convolution added a projected embedding, and the sum over b in
 // batch order (the order of col_sum_kernel) is the bias gradient.  The fused q/k/v projection writes its three biases.
-// Same sums in the same order as the kernels it replaces: the gradients keep their bits.
+// (Until round 3 the same sums in the same order as the kernels it replaced; the 16-byte loads sum a plane in another order.)
 // (sixteen waves per channel: with four, a 64-channel layer at batch 32 was 64 blocks walking 8 planes each -- 47 us)
 __global__ void __launch_bounds__(1024) bias_grad_kernel(const float* __restrict__ dy, int B, int C, int HW, float* __restrict__ db0,
                                                          float* __restrict__ db1, float* __restrict__ db2, int split,
@@ -466,7 +466,17 @@ __global__ void __launch_bounds__(1024) bias_grad_kernel(const float* __restrict
     for (int b = wave; b < B; b += 16) {
         const float* src = dy + ((size_t)b * C + c) * HW;
         float s = 0.0f;
-        for (int i = lane; i < HW; i += 64) s += src[i];
+        if ((HW & 3) == 0) {          // 16 bytes per lane and load, four running sums (round 3: a quarter of the load instructions)
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            for (int i = lane; i < (HW >> 2); i += 64) {
+                const float4 v = src4[i];
+                s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+            }
+            s = (s0 + s1) + (s2 + s3);
+        } else {
+            for (int i = lane; i < HW; i += 64) s += src[i];
+        }
         s = wave_sum_t(s);
         if (lane == 0) S[b] = s;
     }
