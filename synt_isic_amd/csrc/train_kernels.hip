@@ -299,6 +299,47 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The same sums, element by element in the same order, FOUR consecutive elements per thread (16-byte loads and stores: the
+// one-element form reads its slabs in 128-byte pieces); for n and split that are multiples of 4.
+__global__ void __launch_bounds__(256) wgrad_reduce4_kernel(const float4* __restrict__ part, int ksplit, size_t n4,
+                                                            float4* __restrict__ out, float4* __restrict__ out1,
+                                                            float4* __restrict__ out2, size_t split4) {
+    __shared__ float4 red[8][32];
+    const int seg = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int per = (ksplit + 7) / 8;
+    const int k0 = min(seg * per, ksplit), k1 = min(k0 + per, ksplit);
+    for (size_t base = (size_t)blockIdx.x * 32; base < n4; base += (size_t)gridDim.x * 32) {
+        const size_t i = base + j;
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (i < n4) {
+            int k = k0;
+            for (; k + 4 <= k1; k += 4) {
+                const float4 a = part[(size_t)k * n4 + i], b = part[(size_t)(k + 1) * n4 + i];
+                const float4 c = part[(size_t)(k + 2) * n4 + i], d = part[(size_t)(k + 3) * n4 + i];
+                s.x += a.x; s.x += b.x; s.x += c.x; s.x += d.x;
+                s.y += a.y; s.y += b.y; s.y += c.y; s.y += d.y;
+                s.z += a.z; s.z += b.z; s.z += c.z; s.z += d.z;
+                s.w += a.w; s.w += b.w; s.w += c.w; s.w += d.w;
+            }
+            for (; k < k1; ++k) {
+                const float4 a = part[(size_t)k * n4 + i];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+        }
+        red[seg][j] = s;
+        __syncthreads();
+        if (seg == 0 && i < n4) {
+            float4 t = red[0][j];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) { const float4 r = red[g][j]; t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w; }
+            if (split4 == 0 || i < split4) out[i] = t;
+            else if (i < 2 * split4) out1[i - split4] = t;
+            else out2[i - 2 * split4] = t;
+        }
+        __syncthreads();
+    }
+}
+
 template <int KS, int STRIDE, int TR, int TC>
 static int launch_wgrad_cfg(sisic_ctx* ctx, WgradParams& p, hipStream_t s) {
     using G = WgradGeom<KS, STRIDE, TR, TC>;
@@ -380,9 +421,18 @@ int launch_conv_wgrad(sisic_ctx* ctx, const WgradArgs& a, float* part, size_t pa
             SISIC_TRY((launch_wgrad_cfg<3, 1, 8, 8>(ctx, p, s)));
         }
     }
+    const size_t split = a.dw1 ? n / 3 : (size_t)0;
+    const auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if ((n & 3) == 0 && (split & 3) == 0 && al16(part) && al16(a.dw) && al16(a.dw1) && al16(a.dw2)) {
+        const size_t n4 = n >> 2;
+        const int blocks = (int)std::min<size_t>((n4 + 31) / 32, 8192);
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(part), p.ksplit, n4,
+                           reinterpret_cast<float4*>(a.dw), reinterpret_cast<float4*>(a.dw1), reinterpret_cast<float4*>(a.dw2), split >> 2);
+        SISIC_HIP(hipGetLastError());
+        return SISIC_OK;
+    }
     const int blocks = (int)std::min<size_t>((n + 31) / 32, 8192);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, p.ksplit, n, a.dw, a.dw1, a.dw2,
-                       a.dw1 ? n / 3 : (size_t)0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, p.ksplit, n, a.dw, a.dw1, a.dw2, split);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
