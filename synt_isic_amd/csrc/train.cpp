@@ -266,12 +266,22 @@ struct Bwd {
         // fused projection of the 22 residual blocks
         SISIC_TRY(launch_linear_wgrad(u->ctx, tr->dtproj, R, u->temb_act, B, R, Hd, dWf, s));
         SISIC_TRY(launch_col_sums(u->ctx, tr->dtproj, B, R, R, dbf, 0, s));
-        for (ResnetW* r : unet_resnets(u)) {
-            SISIC_HIP(hipMemcpyAsync(grad_of(u, r->temb_w_idx), dWf + (size_t)r->temb_off * Hd, (size_t)r->cout * Hd * sizeof(float),
-                                     hipMemcpyDeviceToDevice, s));
-            SISIC_HIP(hipMemcpyAsync(grad_of(u, r->temb_b_idx), dbf + r->temb_off, (size_t)r->cout * sizeof(float),
-                                     hipMemcpyDeviceToDevice, s));
+        // the 22 blocks' slices of the fused gradient to their own tensors: ONE launch over a job table (44 device copies before)
+        if (!tr->scatter_dev || tr->scatter_src != dWf) {
+            std::vector<PackJob> jobs;
+            for (ResnetW* r : unet_resnets(u)) {
+                jobs.push_back(pack_job_copy(dWf + (size_t)r->temb_off * Hd, grad_of(u, r->temb_w_idx), (size_t)r->cout * Hd));
+                jobs.push_back(pack_job_copy(dbf + r->temb_off, grad_of(u, r->temb_b_idx), (size_t)r->cout));
+            }
+            int blocks = 0;
+            for (PackJob& j : jobs) { j.first_block = blocks; blocks += pack_job_blocks(j); }
+            SISIC_HIP(hipStreamSynchronize(s));          // (a table in use is not replaced under a running launch)
+            if (tr->scatter_dev) { (void)hipFree(tr->scatter_dev); tr->scatter_dev = nullptr; }
+            SISIC_HIP(hipMalloc(&tr->scatter_dev, std::max<size_t>(jobs.size(), 1) * sizeof(PackJob)));
+            SISIC_HIP(hipMemcpy(tr->scatter_dev, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+            tr->scatter_jobs = (int)jobs.size(); tr->scatter_blocks = blocks; tr->scatter_src = dWf;
         }
+        SISIC_TRY(launch_pack_batch(u->ctx, static_cast<const PackJob*>(tr->scatter_dev), tr->scatter_jobs, tr->scatter_blocks, s));
         // d ta[b][k] = sum_r dtproj[b][r] * Wfused[r][k]; the fused weight is stored transposed: tproj_wt[k][r]
         SISIC_TRY(launch_linear_dgrad(u->ctx, tr->dtproj, R, u->tproj_wt, B, R, Hd, dta, s, /*w_is_transposed=*/1));
         SISIC_TRY(launch_silu_bwd(u->ctx, dta, tr->t2, (size_t)B * Hd, dt2, s));
@@ -360,6 +370,7 @@ int sisic_unet_train_end(sisic_unet* u) {
     for (float* p : {tr->grad, tr->adam_m, tr->adam_v, tr->emb, tr->h1, tr->t2, tr->dtproj, tr->garena, tr->wgrad_part, tr->scratch,
                      tr->small, tr->loss_dev, tr->mse_part})
         if (p) (void)hipFree(p);
+    if (tr->scatter_dev) (void)hipFree(tr->scatter_dev);
     for (void* p : tr->repack_dev)
         if (p) (void)hipFree(p);
     if (tr->flag_dev) (void)hipFree(tr->flag_dev);

@@ -126,6 +126,9 @@ struct TrainState {
     // every re-layout of every weight as three batched launches (repack.hip); rebuilt when the derived buffers move
     void* repack_dev[3] = {nullptr, nullptr, nullptr};     // PackJob tables on the device, one per phase
     int repack_jobs[3] = {0, 0, 0}, repack_blocks[3] = {0, 0, 0};
+    void* scatter_dev = nullptr;          // PackJob table: the fused time-embedding projection's gradient rows -> the 22 blocks' own tensors
+    int scatter_jobs = 0, scatter_blocks = 0;
+    const float* scatter_src = nullptr;   // the scratch address the table was built for
     bool repack_ready = false;
 };
 
