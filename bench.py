@@ -5,6 +5,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started without a rendezvous environment (no WORLD_SIZE), `--gpus N` makes this process a
+LAUNCHER that touches no GPU, starts N children of this same file (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, rendezvous on 127.0.0.1), relays rank 0's single JSON line and exits non-zero if any child does.
+`--dry-run` goes through the same rendezvous, shard, gather, max-over-ranks and JSON line WITHOUT the sampler (gloo when there
+is no GPU): the plumbing of the N > 1 path, testable on a CPU-only machine (tests/test_bench_launcher.py).
+
 Workload = BASELINE.json configs[1]: batch=64 per GPU, 3x64x64, T=1000 DDPM sampling with the reference
 architecture (model_manager.py:173-194), seeded synthetic weights and synthetic Gaussian inputs resident
 in HBM.  One "step" is one pass of the loop body of image_generator.py:400-403 (UNet forward + scheduler
@@ -15,10 +21,14 @@ full run, for smaller K it is the per-step time extrapolated to 1000 steps (all 
 kernels).
 
 Besides the driver's fields the JSON line carries
-  roofline      the dominant kernel family (the stride-1 Winograd F(2x2,3x3) convolutions, 31 launches per step): FLOPs the matrix pipe
-                EXECUTES per launch (Winograd F(2x2,3x3): 16/36 of the direct form) / average launch duration measured
-                with HIP events on the launch stream, vs the fp32 MFMA peak (157.3 TFLOP/s) -- frac <= 1 by construction;
-                the direct-form ("algorithmic") rate and the whole conv3x3 class are reported beside it
+  roofline      the dominant kernel (the stride-1 Winograd F(2x2,3x3) convolutions with fp32-equivalent bf16x3 products, 33
+                launches per step): bf16 FLOPs the kernel ISSUES to the matrix pipe per launch (6 bf16 term products per fp32
+                product of the Winograd algorithm, which itself multiplies 16/36 of the direct form) / average launch duration
+                measured with HIP events on the launch stream, vs the dense bf16 MFMA peak (2500 TFLOP/s) -- the pipe the
+                kernel executes on, frac <= 1 by construction; the fp32-equivalent rate against the f32 peak, the direct-form
+                ("algorithmic") rate, the HBM fraction and the whole conv3x3 class are reported beside it
+  validated     after the clock stops: all timed images finite, and image 0 of the timed batch bit-equal to its own B=1 run of
+                the same K steps (the run fails otherwise)
   cpu_baseline  the CPU oracle (oracle/, torch fp32) timed on this box's host cores on a bounded sample
   e2e_images_per_sec   host-inclusive rate of Sampler.generate_seeds (seeds in -> uint8 images on the host out: x_T and
                 z_t drawn by the per-image CPU generators, uploads, T steps, epilogue, download) -- SURVEY 8(d)'s
@@ -27,14 +37,14 @@ Besides the driver's fields the JSON line carries
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 BATCH_PER_GPU = 64
 SIZE = 64
@@ -56,6 +66,7 @@ def _affinity() -> int:
 
 def _cpu_steps(sd, n_thr: int, B: int, max_steps: int, seconds_budget: float, warm: int = 2):
     """seconds per step of the oracle on n_thr threads: consecutive steps from t=999, `warm` warm-up steps untimed"""
+    import torch
     from oracle import ddpm as oddpm, unet as ounet
     torch.set_num_threads(n_thr)
     g = torch.Generator().manual_seed(0)
@@ -126,6 +137,143 @@ def cpu_baseline(sd, seconds_budget: float = 24.0):
     }
 
 
+def launch_ranks(n: int, argv) -> int:
+    """The launcher of `python bench.py --gpus N` (N > 1, no rendezvous environment): N child processes of this file, one
+    rank per GPU, as torch.distributed.run would start them.  This process makes NO GPU call (it does not even import torch):
+    the children are fresh processes (never an exec from a process that has initialised the GPU).  Rank 0's stdout -- the one
+    JSON line -- is relayed to stdout, the other ranks' stdout and everyone's stderr go to stderr.  Returns the first
+    non-zero exit code of a child (the remaining children are then stopped by their exact PIDs), else 0."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    # rank 0 prints one short line (far below the pipe's buffer), so the children are simply polled until all have exited
+    # or one has failed
+    rc = 0
+    try:
+        while rc == 0 and any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            rc = next((p.returncode for p in procs if p.poll() is not None and p.returncode != 0), 0)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()                     # exact PIDs of the children this process started
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    if rc == 0:
+        rc = next((p.returncode for p in procs if p.returncode != 0), 0)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    # (libraries may write to a rank's stdout too -- gloo announces its connections there: only the JSON line is relayed to
+    #  stdout, the rest goes to stderr)
+    lines = []
+    for ln in out0.splitlines():
+        if ln.lstrip().startswith("{"):
+            lines.append(ln)
+            print(ln, flush=True)
+        elif ln.strip():
+            print(ln, file=sys.stderr, flush=True)
+    if rc == 0 and len(lines) != 1:
+        print(f"[bench launcher] rank 0 printed {len(lines)} lines, expected one JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def dry_run(args, log) -> None:
+    """The N-rank plumbing without the sampler: init_from_env -> shard_range -> stand-in uint8 images derived from the seeds ->
+    gather_images -> max_over_ranks -> ONE JSON line of the bench schema (value / roofline / cpu_baseline null).  gloo when
+    there is no GPU (this container), RCCL on a GPU box."""
+    import torch
+    from synt_isic_amd import dist as sdist
+    rank, world, local = sdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    on_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    B = args.batch
+    lo, hi = sdist.shard_range(B * world, world, rank)
+    if os.environ.get("SISIC_BENCH_DRY_FAIL_RANK") == str(rank):      # tests/test_bench_launcher.py: a rank that dies
+        raise SystemExit(3)
+
+    def fake(seeds):
+        out = torch.empty((len(seeds), SIZE, SIZE, 3), dtype=torch.uint8)
+        for i, sd in enumerate(seeds):
+            out[i] = torch.full((SIZE, SIZE, 3), int(sd) % 251, dtype=torch.uint8)
+            out[i, 0, 0, 0] = int(sd) // 251 % 256
+        return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    local_images = fake(range(lo, hi)).to(dev)
+    gathered = sdist.gather_images(local_images, B * world, dst=0)
+    barrier()
+    elapsed = sdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        assert gathered.shape == (B * world, SIZE, SIZE, 3)
+        assert torch.equal(gathered.cpu(), fake(range(B * world))), "gathered images are not the unsharded batch in seed order"
+        log(f"dry run: {world} ranks, gather of {B * world} stand-in images in {elapsed * 1e3:.1f} ms")
+        print(json.dumps(bench_line(value=None, world=world, K=args.steps, W=args.warmup, ms_per_step=None, B=B,
+                                    roofline=None, cpu=None, e2e=None, validated=None, dry_run=True,
+                                    backend=torch.distributed.get_backend() if world > 1 else None)), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def bench_line(*, value, world, K, W, ms_per_step, B, roofline, cpu, e2e, validated, dry_run=False, backend=None):
+    line = {
+        "metric": "images/sec at 3x64x64 T=1000 (DDPM reverse-diffusion sampling)",
+        "value": value,
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "dtype_note": "fp32 storage, accumulation and results; the stride-1 conv3x3 and 1x1 kernels form each fp32 product from six "
+                      "exact bf16 term products on the bf16 MFMA (roofline.products) -- same measured error against float64 "
+                      "as the f32 MFMA kernels they replace (SISIC_WINO_BF16X3=0 SISIC_POINTWISE_BF16X3=0 run those).  Domain: "
+                      "finite inputs and weights of any fp32 magnitude whose products and sums stay in the normal fp32 range "
+                      "(tests/test_gpu_kernels.py::test_bf16x3_scale_sweep: 1e-6 ... 1e4, mixed magnitudes inside one reduction, at "
+                      "the same relative bound); a non-finite input yields NaN where fp32 arithmetic yields Inf or NaN "
+                      "(test_bf16x3_non_finite_inputs)",
+        "data": "synthetic",
+        "config": {"workload": f"batch={B} per GPU, 3x{SIZE}x{SIZE}, T={T_FULL} DDPM sampling "
+                               f"(BASELINE configs[1]{'; configs[2] sharding' if world > 1 else ''})",
+                   "batch_per_gpu": B, "global_batch": B * world, "T": T_FULL, "steps_timed": K,
+                   "parallelism": f"independent seeds x{world}, one gather of uint8 images"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "e2e_images_per_sec": e2e["images_per_sec"] if e2e else None,
+        "e2e": e2e,
+        "validated": validated,
+        "multi_gpu_note": "no 1->8 GPU scaling curve has been measured by the builder (one-GPU boxes only); N>1 runs "
+                          "are the driver's (`python bench.py --gpus N` starts its own N ranks; the torch.distributed.run form works too)",
+    }
+    if dry_run:
+        line["dry_run"] = True
+        line["backend"] = backend
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,20 +286,32 @@ def main():
     ap.add_argument("--e2e-steps", type=int, default=0,
                     help="steps of the host-inclusive leg (default: max(--steps, 256), independent of a short --steps: with "
                          "20 steps the leg measures its fixed costs, not the rate)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous, shard, gather, max over ranks and the JSON line without the sampler (gloo when there is no GPU)")
+    ap.add_argument("--no-validate", action="store_true", help="skip the post-clock check of the timed images")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no rendezvous environment: this process is the launcher and touches no GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    def log(msg):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    if args.dry_run:
+        dry_run(args, log)
+        return
+
+    import torch
     from synt_isic_amd import dist as sdist
     from synt_isic_amd import ops
     from synt_isic_amd.sampler import Sampler, run_sampling_loop
     from synt_isic_amd.weights import synthetic_unet_state_dict
 
-    def log(msg):
-        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
-
     rank, world, local = sdist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start `python bench.py --gpus {world}` (it launches its own "
+                         f"ranks) or torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local)
@@ -198,6 +358,23 @@ def main():
     ms_per_step = elapsed * 1e3 / K
     value = B * world / (ms_per_step * 1e-3 * T_FULL)
     log(f"timed {K} steps: {ms_per_step:.3f} ms/step -> {value:.3f} images/sec")
+
+    # ---- after the clock has stopped: are the timed images the right images?  Every latent of the timed batch is finite, and
+    # image 0 re-sampled ALONE (B = 1, the same x_T, the same noise, the same K steps) has the same bits -- an image's chain
+    # depends on its own inputs only, so any kernel that mixed images, skipped work for part of the batch
+    # or read another batch's buffers shows here.  Every rank checks its own shard; a failure ends the run non-zero.
+    validated = None
+    if not args.no_validate:
+        finite = bool(torch.isfinite(res.latents).all().item())
+        one = run_sampling_loop(model, sched, x_T[:1].contiguous(), z[:, :1].contiguous() if z.shape[0] else z[:, :1])
+        same_x = bool(torch.equal(one.latents[0], res.latents[0]))
+        same_u8 = bool(torch.equal(one.images[0], res.images[0]))
+        spread = int(res.images.to(torch.int32).amax().item() - res.images.to(torch.int32).amin().item())
+        validated = {"all_latents_finite": finite, "image0_bit_equal_to_its_B1_run": same_x and same_u8, "steps": K,
+                     "uint8_range_of_batch": spread}
+        if not (finite and same_x and same_u8 and one.steps_done == K):
+            raise SystemExit(f"bench validation failed on rank {rank}: {validated}")
+        log(f"validated: {validated}")
 
     # ---- host-inclusive leg (every rank at once, so that at N > 1 the ranks' CPU noise producers compete for the host
     # as they would in a real sharded run): seeds in -> uint8 images on the host out, KE steps of a KE-step grid
@@ -255,7 +432,7 @@ def main():
         # the committed counter passes of this same command (tools/prof_pmc.sh + tools/make_pmc_summary.py); the newest
         # round's summary that exists is used and named in traffic_source.
         traffic, traffic_src, traffic_class = None, None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             path = os.path.join(ROOT, "profiles", rnd, "pmc_summary.json")
             try:
                 with open(path) as f:
@@ -282,7 +459,8 @@ def main():
         try:
             import csv
             import re
-            rp_rnd = "r03" if os.path.exists(os.path.join(ROOT, "profiles", "r03", "bench_steps20_kernel_stats.csv")) else "r02"
+            rp_rnd = next((r for r in ("r04", "r03", "r02")
+                           if os.path.exists(os.path.join(ROOT, "profiles", r, "bench_steps20_kernel_stats.csv"))), "r02")
             path = os.path.join(ROOT, "profiles", rp_rnd, "bench_steps20_kernel_stats.csv")
             tot_ns, calls = 0.0, 0
             with open(path) as f:
@@ -298,27 +476,32 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         if bf3:
-            # six bf16 term products per fp32 product (three MFMAs of two); the bf16 pipe's dense peak from the guide
+            # six bf16 term products per fp32 product (three MFMAs of two); the bf16 pipe's dense peak from the guide: the
+            # pipe the kernel EXECUTES on, so frac <= 1 by construction
             issued = 6.0 * d_exec
             head = {
                 "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) with fp32-equivalent products on "
                           "v_mfma_f32_32x32x16_bf16 (every operand split exactly into three bf16 terms, six of the nine term "
                           "products, fp32 accumulate; GroupNorm+SiLU prologue, bias/temb/residual + GroupNorm partials epilogue): "
-                          "conv_winograd_bf3_kernel<PRO>, 64 channels x 16x16 pixels per workgroup, one per CU",
+                          + dom.get("kernel_name", "conv_winograd_bf3*_kernel<PRO>") + ", 64 channels x 16x16 pixels per workgroup, one per CU",
                 "bound": "mfma",
-                "achieved": d_exec,
-                "peak": PEAK_FP32_MFMA_TFLOPS,
+                "pipe": "bf16 (v_mfma_f32_32x32x16_bf16, dense)",
+                "achieved": issued,
+                "peak": PEAK_BF16_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": d_exec / PEAK_FP32_MFMA_TFLOPS,
-                "achieved_is": "fp32 multiply-adds x 2 of the Winograd algorithm (16/36 of the direct form's 2*MAC) / HIP-event launch "
-                               "time, against the f32 MFMA peak -- the rate an f32-pipe kernel would need; the kernel itself issues "
-                               "six bf16 products per fp32 product to the bf16 pipe: see bf16_pipe",
-                "bf16_pipe": {"issued_TFLOPs": issued, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": issued / PEAK_BF16_MFMA_TFLOPS,
-                              "what": "6 x the fp32-equivalent rate against the dense bf16 MFMA peak (MI355X_MICROARCH.md)"},
+                "frac": issued / PEAK_BF16_MFMA_TFLOPS,
+                "achieved_is": "bf16 FLOPs ISSUED to the matrix pipe: 6 bf16 term products per fp32 product x 2 x the fp32 "
+                               "multiply-adds of the Winograd algorithm (16/36 of the direct form's MACs) / HIP-event launch time, "
+                               "against the dense bf16 MFMA peak (MI355X_MICROARCH.md) -- <= 1 by construction",
+                "fp32_equivalent_TFLOPs": d_exec,
+                "fp32_equivalent_vs_f32_peak": d_exec / PEAK_FP32_MFMA_TFLOPS,
+                "fp32_equivalent_is": "the same launches priced as the fp32 multiply-adds x 2 they stand for, against the f32 MFMA "
+                                      "peak (157.3): the rate an f32-pipe kernel would need to match this one; not a utilisation",
                 "products": "bf16x3: x = hi + mid + lo exactly (8 + 8 + 8 significant bits), hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + "
                             "lo*hi summed in the MFMA's fp32 accumulator; measured error against float64 equal to the f32-MFMA "
                             "forms' (tests/test_gpu_kernels.py: 1.5-2.1e-7 relative, bound 1e-5)",
             }
+            peak_for_rp = PEAK_BF16_MFMA_TFLOPS / 6.0
         else:
             head = {
                 "kernel": "stride-1 conv3x3 at 64^2/32^2/16^2 as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 (GroupNorm+SiLU prologue, "
@@ -333,13 +516,14 @@ def main():
                 "achieved_is": "FLOPs issued to the matrix pipe (16/36 of the direct form's 2*MAC) / HIP-event launch time; "
                                "<= 1 of the f32 MFMA peak by construction",
             }
+            peak_for_rp = PEAK_FP32_MFMA_TFLOPS
         roofline = {
             **head,
             "traffic": traffic,
             "traffic_source": traffic_src,
             "avg_launch_us": dom["ms"] * 1e3 / n_dom,
             "rocprofv3_avg_launch_us": rp_us,
-            "rocprofv3_frac": (dom["flops_executed"] / n_dom / (rp_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if rp_us else None,
+            "rocprofv3_frac": (dom["flops_executed"] / n_dom / (rp_us * 1e-6) / 1e12 / peak_for_rp) if rp_us else None,
             "rocprofv3_source": rp_src,
             "launches": dom["launches"],
             "launches_per_step": dom["launches"] / n_prof,
@@ -349,6 +533,7 @@ def main():
             "algorithmic_bytes_per_launch": dom["bytes"] / n_dom,
             "algorithmic_GBps": d_gbps,
             "hbm_frac": d_gbps / PEAK_HBM_GBPS,
+            "traffic_over_algorithmic": (traffic / (dom["bytes"] / n_dom)) if traffic else None,
             "conv3x3_class": {                               # all 52 conv3x3 launches of a step (every kernel they use)
                 "launches_per_step": c3["launches"] / n_prof,
                 "ms_per_step": c3["ms"] / n_prof,
@@ -362,40 +547,15 @@ def main():
             },
             "per_step_ms": {k: v["ms"] / n_prof for k, v in prof.items()},
         }
-        log(f"dominant kernel: {d_exec:.1f} executed TFLOP/s = {d_exec / PEAK_FP32_MFMA_TFLOPS:.3f} of the f32 MFMA peak "
-            f"({dom['ms'] * 1e3 / n_dom:.1f} us/launch); conv3x3 class {tflops_exec:.1f} executed / {tflops:.1f} algorithmic")
+        log(f"dominant kernel: {head['achieved']:.1f} TFLOP/s issued = {head['frac']:.3f} of its pipe's peak ({head['peak']:.0f}); "
+            f"{d_exec:.1f} fp32-equivalent TFLOP/s ({dom['ms'] * 1e3 / n_dom:.1f} us/launch); conv3x3 class {tflops_exec:.1f} executed / {tflops:.1f} algorithmic")
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(sd)
             log(f"cpu baseline: {cpu['value']:.5f} images/sec on {cpu['cores']} threads")
 
     if rank == 0:
-        line = {
-            "metric": "images/sec at 3x64x64 T=1000 (DDPM reverse-diffusion sampling)",
-            "value": value,
-            "unit": "images/sec",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": W,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "dtype_note": "fp32 storage, accumulation and results; the stride-1 conv3x3 kernel forms each fp32 product from six "
-                          "exact bf16 term products on the bf16 MFMA (roofline.products) -- same measured error against float64 "
-                          "as the f32 MFMA kernels it replaces (SISIC_WINO_BF16X3=0 runs those)",
-            "data": "synthetic",
-            "config": {"workload": f"batch={B} per GPU, 3x{SIZE}x{SIZE}, T={T_FULL} DDPM sampling "
-                                   f"(BASELINE configs[1]{'; configs[2] sharding' if world > 1 else ''})",
-                       "batch_per_gpu": B, "global_batch": B * world, "T": T_FULL, "steps_timed": K,
-                       "parallelism": f"independent seeds x{world}, one gather of uint8 images"},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "e2e_images_per_sec": e2e["images_per_sec"] if e2e else None,
-            "e2e": e2e,
-            "multi_gpu_note": "no 1->8 GPU scaling curve has been measured by the builder (one-GPU boxes only); N>1 runs "
-                              "are the driver's",
-        }
+        line = bench_line(value=value, world=world, K=K, W=W, ms_per_step=ms_per_step, B=B, roofline=roofline, cpu=cpu, e2e=e2e,
+                          validated=validated)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

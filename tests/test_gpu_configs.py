@@ -177,13 +177,16 @@ def test_bench_line_contract():
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["scaling"] == "weak"
     assert abs(d["value"] - 64.0 / (d["ms_per_step"] * 1e-3 * 1000)) < 1e-6 * d["value"]       # images/sec of a T=1000 run
     rf = d["roofline"]
-    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
-    # the fp32-equivalent rate against the f32 MFMA peak (the bf16x3 kernel may exceed what the f32 pipe could deliver; its
-    # own pipe's utilisation is reported beside it and is <= 1 by construction)
-    assert 0.3 < rf["frac"] < 2.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert abs(rf["achieved"] - rf["executed_flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
-    bp = rf["bf16_pipe"]
-    assert bp["peak"] == 2500.0 and abs(bp["issued_TFLOPs"] - 6.0 * rf["achieved"]) < 1e-6 * bp["issued_TFLOPs"] and 0.05 < bp["frac"] <= 1.0
+    # the dominant kernel runs on the bf16 matrix pipe: frac = bf16 FLOPs issued / the dense bf16 peak, <= 1 by construction
+    # (ADVICE r03); the fp32-equivalent rate against the f32 peak is a separately named field, not a utilisation
+    assert rf["bound"] == "mfma" and rf["pipe"].startswith("bf16") and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert 0.05 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["achieved"] - 6.0 * rf["executed_flops_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e12) < 1e-6 * rf["achieved"]
+    assert abs(rf["fp32_equivalent_TFLOPs"] * 6.0 - rf["achieved"]) < 1e-6 * rf["achieved"]
+    assert abs(rf["fp32_equivalent_vs_f32_peak"] - rf["fp32_equivalent_TFLOPs"] / 157.3) < 1e-9
+    assert 0.0 < rf["hbm_frac"] < 1.0 and (rf["traffic_over_algorithmic"] is None or rf["traffic_over_algorithmic"] > 0.9)
+    v = d["validated"]
+    assert v["all_latents_finite"] is True and v["image0_bit_equal_to_its_B1_run"] is True and v["steps"] == 6
     assert rf["launches_per_step"] == BF3_LAUNCHES_PER_STEP and "traffic" in rf and "traffic_source" in rf
     # (`traffic` and `rocprofv3_avg_launch_us` come from committed profiler files of another run and are labelled so in the
     #  line; comparing a live timing with them belongs to the measurement script, not to a correctness test -- ADVICE r02)
