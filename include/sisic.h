@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define SISIC_ABI_VERSION 1
+/* 2 (round 4): sisic_sample_frames added; the packed-filter buffers grew in round 3 (1x1: three layouts = 3.5 x the
+ * [Cin_pad][1][Cout_pad] floats; Winograd: the f32 U plus the bf16x3 split of it) -- ALWAYS size them with the *_numel
+ * functions below, never from the layout comment. */
+#define SISIC_ABI_VERSION 2
 
 #define SISIC_OK 0
 #define SISIC_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -98,13 +101,17 @@ typedef struct sisic_conv_args {
 int sisic_conv_stats_slots(const sisic_conv_args* args);
 
 /* Winograd-domain filters U = G g G^T of an OIHW 3x3 weight, computed in float64:
- * number of floats, and dev OIHW -> dev packed [Cin_pad][16][Cout_pad].                      */
+ * number of floats, and dev OIHW -> dev packed [Cin_pad][16][Cout_pad], FOLLOWED by the same filters split into three bf16
+ * terms in the operand order of the bf16x3 kernels (pack_device.h).  The buffer must hold sisic_conv_winograd_numel floats:
+ * more than the f32 layout alone.                                                             */
 int64_t sisic_conv_winograd_numel(int Cout, int Cin);
 int sisic_conv_winograd_pack(sisic_ctx*, const float* w_oihw, int Cout, int Cin, float* u_packed, void* stream);
 
-/* number of floats of the packed form of an OIHW weight [Cout,Cin,k,k] */
+/* number of floats of the packed form of an OIHW weight [Cout,Cin,k,k] (-1: unsupported ksize).  For ksize 1 this is 3.5 x
+ * the [Cin_pad][1][Cout_pad] layout: the direct kernel's, the pointwise kernel's and the bf16x3 split are all written. */
 int64_t sisic_conv_packed_numel(int Cout, int Cin, int ksize);
-/* dev OIHW -> dev packed [Cin_pad][k*k][Cout_pad], zero padded */
+/* dev OIHW -> dev packed [Cin_pad][k*k][Cout_pad] (+ the further layouts above), zero padded; w_packed must hold
+ * sisic_conv_packed_numel floats */
 int sisic_conv_pack_weights(sisic_ctx*, const float* w_oihw, int Cout, int Cin, int ksize,
                             float* w_packed, void* stream);
 int sisic_conv2d(sisic_ctx*, const sisic_conv_args* args, void* stream);
@@ -208,6 +215,13 @@ int sisic_unet_forward(sisic_unet*, const float* sample, const int64_t* timestep
 int sisic_sample(sisic_unet*, float* x, int B, int H, int W, int T, const int64_t* timesteps,
                  const float* coef, float clip, const float* noise, float* traj, uint8_t* out_u8,
                  const volatile int* cancel, int* steps_done, void* stream);
+/* The same loop keeping only SOME frames of the trajectory (xai/XAI.py:751-757 `save_indices`, :815-826: every N-th step and
+ * the last one, or the steps whose t is a multiple of N): traj_row is a host int [T], traj_row[i] = the row of traj that
+ * receives x after step i, or -1 for a step that is not kept (traj must hold max(traj_row)+1 rows of B*C*H*W floats).
+ * traj_row NULL keeps every step in row i (= sisic_sample).                                                              */
+int sisic_sample_frames(sisic_unet*, float* x, int B, int H, int W, int T, const int64_t* timesteps,
+                        const float* coef, float clip, const float* noise, float* traj, const int* traj_row,
+                        uint8_t* out_u8, const volatile int* cancel, int* steps_done, void* stream);
 
 /* ---- training step (diffusion/train_diffusion.py:201-266) -----------------------------------
  * fp32 throughout.  The reference wraps the forward in torch.cuda.amp.autocast() (fp16 matmuls/convolutions) and scales the

@@ -14,6 +14,8 @@ _LIB_PATH = os.environ.get("SISIC_LIB_PATH") or os.path.join(os.path.dirname(os.
                                                              "libsisic_hip.so")
 _lib: Optional[C.CDLL] = None
 
+ABI_VERSION = 2          # include/sisic.h SISIC_ABI_VERSION
+
 SISIC_OK = 0
 SISIC_EINVAL = -1
 SISIC_EHIP = -2
@@ -90,6 +92,9 @@ SIGNATURES = {
     "sisic_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int64_p, c_float_p,
                                C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                C.c_void_p]),
+    "sisic_sample_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int64_p, c_float_p,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int), C.c_void_p]),
     "sisic_unet_train_begin": (C.c_int, [C.c_void_p]),
     "sisic_unet_train_end": (C.c_int, [C.c_void_p]),
     "sisic_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -156,8 +161,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.sisic_abi_version() != 1:
-        raise RuntimeError(f"libsisic_hip.so ABI {lib.sisic_abi_version()} != 1; rebuild the library")
+    if lib.sisic_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libsisic_hip.so ABI {lib.sisic_abi_version()} != {ABI_VERSION}; rebuild the library")
     _lib = lib
     return lib
 

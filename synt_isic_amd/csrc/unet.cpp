@@ -764,7 +764,7 @@ static int loop_step(sisic_unet* u, int B, int H, int W, size_t n, float clip, h
 // The loop as ONE captured step replayed T-1 times (hipGraph): at batch 1 a step is ~190 launches of 5-20 us kernels and
 // the host cannot issue them as fast as the GPU retires them (measured: 3.0 ms of kernels in a 4.5 ms step).
 static int sample_graph(sisic_unet* u, float* x, int B, int H, int W, int T, const float* coef, float clip, const float* noise,
-                        float* traj, const volatile int* cancel, int* steps_done, hipStream_t caller) {
+                        float* traj, const int* traj_row, const volatile int* cancel, int* steps_done, hipStream_t caller) {
     const int C = u->cfg.in_channels;
     const size_t n = (size_t)B * C * H * W;
     SISIC_REQUIRE(T <= 1000, "sample: at most 1000 steps per call");
@@ -794,7 +794,8 @@ static int sample_graph(sisic_unet* u, float* x, int B, int H, int W, int T, con
     SISIC_HIP(hipMemcpyAsync(u->x_work, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
 
     auto after_step = [&](int i) -> int {
-        if (traj) SISIC_HIP(hipMemcpyAsync(traj + (size_t)i * n, u->x_work, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        const int row = traj_row ? traj_row[i] : i;          // (kept frames only: XAI.py:751-757 save_indices)
+        if (traj && row >= 0) SISIC_HIP(hipMemcpyAsync(traj + (size_t)row * n, u->x_work, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (steps_done) *steps_done = i + 1;
         return SISIC_OK;
     };
@@ -865,7 +866,16 @@ static int sample_graph(sisic_unet* u, float* x, int B, int H, int W, int T, con
 int sisic_sample(sisic_unet* u, float* x, int B, int H, int W, int T, const int64_t* timesteps, const float* coef,
                  float clip, const float* noise, float* traj, uint8_t* out_u8, const volatile int* cancel,
                  int* steps_done, void* stream) {
+    return sisic_sample_frames(u, x, B, H, W, T, timesteps, coef, clip, noise, traj, nullptr, out_u8, cancel, steps_done, stream);
+}
+
+int sisic_sample_frames(sisic_unet* u, float* x, int B, int H, int W, int T, const int64_t* timesteps, const float* coef,
+                        float clip, const float* noise, float* traj, const int* traj_row, uint8_t* out_u8,
+                        const volatile int* cancel, int* steps_done, void* stream) {
     SISIC_REQUIRE(u && x && timesteps && coef && T > 0, "sample: null argument");
+    SISIC_REQUIRE(!traj_row || traj, "sample: traj_row without a trajectory buffer");
+    if (traj_row)
+        for (int i = 0; i < T; ++i) SISIC_REQUIRE(traj_row[i] >= -1, "sample: traj_row[%d] = %d (a row of traj, or -1)", i, traj_row[i]);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (steps_done) *steps_done = 0;
     SISIC_TRY(check_shape(u, B, H, W));
@@ -886,7 +896,7 @@ int sisic_sample(sisic_unet* u, float* x, int B, int H, int W, int T, const int6
     const bool use_graph = (u->graph_mode < 0 ? u->latency_mode : u->graph_mode != 0) && !u->ctx->profiling && T >= 4 && T <= 1000;
     if (use_graph) {
         if (!s) SISIC_HIP(hipStreamSynchronize(s));           // the embeddings above ran on the default stream
-        const int rc = sample_graph(u, x, B, H, W, T, coef, clip, noise, traj, cancel, steps_done, s);
+        const int rc = sample_graph(u, x, B, H, W, T, coef, clip, noise, traj, traj_row, cancel, steps_done, s);
         if (rc != SISIC_OK) return rc;
         if (out_u8) SISIC_TRY(launch_denorm_u8(u->ctx, x, out_u8, B, C, H, W, s));
         return SISIC_OK;
@@ -907,7 +917,8 @@ int sisic_sample(sisic_unet* u, float* x, int B, int H, int W, int T, const int6
         const float* z = nullptr;
         if (noise && c[4] != 0.0f) z = noise + (zi++) * n;
         SISIC_TRY(launch_ddpm_step(u->ctx, u->eps_buf, x, z, x, (int64_t)n, c[0], c[1], c[2], c[3], c[4], clip, s));
-        if (traj) SISIC_HIP(hipMemcpyAsync(traj + (size_t)i * n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        const int row = traj_row ? traj_row[i] : i;
+        if (traj && row >= 0) SISIC_HIP(hipMemcpyAsync(traj + (size_t)row * n, x, n * sizeof(float), hipMemcpyDeviceToDevice, s));
         if (steps_done) *steps_done = i + 1;
     }
     if (out_u8) SISIC_TRY(launch_denorm_u8(u->ctx, x, out_u8, B, C, H, W, s));

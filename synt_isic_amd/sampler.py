@@ -185,11 +185,33 @@ class NoiseStream:
                     self.ready[slot].synchronize()
 
 
+def trajectory_save_indices(timesteps: Sequence[int], save_every: int) -> List[int]:
+    """Which steps of a run the XAI trajectory keeps (xai/XAI.py:751-777 `save_indices`, :815-822): every
+    ``save_every``-th step by index and always the last one; when ``save_every`` is not smaller than the number of steps
+    it is read as a stride in t instead: the steps nearest to t = 0, max(t) and the multiples of ``save_every`` up to 1000,
+    and every step whose own t is such a multiple (or 0).  Sorted step indices."""
+    ts = [int(float(t)) for t in timesteps]
+    n = len(ts)
+    every = int(save_every)
+    if every <= 0:
+        raise ValueError("save_every must be positive")
+    keep = set(range(0, n, every))
+    if n:
+        keep.add(n - 1)
+    if every >= n and n:
+        want = {0, max(ts)} | set(range(0, 1001, every))
+        for dt in want:
+            keep.add(min(range(n), key=lambda i: abs(ts[i] - dt)))
+        keep |= {i for i, t in enumerate(ts) if t % every == 0 or t == 0}
+    return sorted(keep)
+
+
 @dataclass
 class SampleResult:
     images: torch.Tensor                       # uint8 [B,H,W,3] on the GPU
     latents: torch.Tensor                      # fp32 [B,3,H,W] final x_0 on the GPU
-    trajectory: Optional[torch.Tensor] = None  # fp32 [T,B,3,H,W] on the GPU
+    trajectory: Optional[torch.Tensor] = None  # fp32 [n_kept,B,3,H,W] on the GPU: x after the steps of trajectory_steps
+    trajectory_steps: List[int] = field(default_factory=list)   # step indices of the kept frames (all T without a stride)
     seeds: List[int] = field(default_factory=list)
     noise_hashes: List[str] = field(default_factory=list)
     timesteps: List[int] = field(default_factory=list)
@@ -197,14 +219,29 @@ class SampleResult:
     cancelled: bool = False                    # the stop flag ended the loop early: images/latents are NOT a result
 
 
+def _frame_rows(T: int, return_trajectory: bool, save_indices: Optional[Sequence[int]]):
+    """(kept step indices, host int32 [T] row table or None) for sisic_sample_frames"""
+    if not return_trajectory:
+        return [], None
+    if save_indices is None:
+        return list(range(T)), None
+    kept = sorted({int(i) for i in save_indices})
+    if kept and (kept[0] < 0 or kept[-1] >= T):
+        raise ValueError(f"save_indices outside 0..{T - 1}")
+    rows = np.full((T,), -1, dtype=np.int32)
+    rows[kept] = np.arange(len(kept), dtype=np.int32)
+    return kept, rows
+
+
 @torch.no_grad()
 def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch.Tensor,
-                      noise, *, return_trajectory: bool = False,
+                      noise, *, return_trajectory: bool = False, save_indices: Optional[Sequence[int]] = None,
                       cancel_flag: Optional[C.c_int] = None) -> SampleResult:
     """x_T: GPU fp32 [B,C,H,W]; noise: GPU fp32 [n_noise,B,C,H,W], None (no noise added), or a ``NoiseStream``
-    (the loop then runs segment by segment while the stream draws and uploads the next segment's noise)."""
+    (the loop then runs segment by segment while the stream draws and uploads the next segment's noise).
+    return_trajectory keeps x after every step, or after the steps in ``save_indices`` only (``trajectory_save_indices``)."""
     if isinstance(noise, NoiseStream):
-        return _run_streamed(model, scheduler, x_T, noise, return_trajectory, cancel_flag)
+        return _run_streamed(model, scheduler, x_T, noise, return_trajectory, cancel_flag, save_indices)
     lib = _lib.load()
     dev = x_T.device
     if dev.type != "cuda":
@@ -219,22 +256,25 @@ def run_sampling_loop(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: t
             raise ValueError(f"noise must be fp32 {(n_noise, B, Cc, H, W)} on {dev}, got {tuple(noise.shape)}")
         noise = noise.contiguous()
     x = x_T.to(torch.float32).contiguous().clone()
-    traj = torch.empty((T, B, Cc, H, W), dtype=torch.float32, device=dev) if return_trajectory else None
+    kept, rows = _frame_rows(T, return_trajectory, save_indices)
+    traj = torch.empty((len(kept), B, Cc, H, W), dtype=torch.float32, device=dev) if return_trajectory else None
     out_u8 = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=dev)
     done = C.c_int(0)
     clip = scheduler.config.clip_sample_range if scheduler.config.clip_sample else 0.0
-    rc = lib.sisic_sample(model.handle, x.data_ptr(), B, H, W, T,
-                          C.cast(ts.data_ptr(), _lib.c_int64_p), C.cast(coef.data_ptr(), _lib.c_float_p),
-                          float(clip), noise.data_ptr() if noise is not None else None,
-                          traj.data_ptr() if traj is not None else None, out_u8.data_ptr(),
-                          C.byref(cancel_flag) if cancel_flag is not None else None, C.byref(done),
-                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    rc = lib.sisic_sample_frames(model.handle, x.data_ptr(), B, H, W, T,
+                                 C.cast(ts.data_ptr(), _lib.c_int64_p), C.cast(coef.data_ptr(), _lib.c_float_p),
+                                 float(clip), noise.data_ptr() if noise is not None else None,
+                                 traj.data_ptr() if traj is not None and len(kept) else None,
+                                 rows.ctypes.data_as(C.POINTER(C.c_int)) if rows is not None and len(kept) else None,
+                                 out_u8.data_ptr(),
+                                 C.byref(cancel_flag) if cancel_flag is not None else None, C.byref(done),
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != _lib.SISIC_ECANCEL:
         check(rc)
     cancelled = rc == _lib.SISIC_ECANCEL
     if cancelled:
         out_u8.zero_()                         # never hand uninitialised pixels to a caller that ignores `cancelled`
-    return SampleResult(images=out_u8, latents=x, trajectory=traj, timesteps=[int(t) for t in ts],
+    return SampleResult(images=out_u8, latents=x, trajectory=traj, trajectory_steps=kept, timesteps=[int(t) for t in ts],
                         steps_done=done.value, cancelled=cancelled)
 
 
@@ -255,7 +295,8 @@ def segment_bounds(T: int, seg: int, per_step: int) -> List[int]:
 
 
 def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch.Tensor, ns: NoiseStream,
-                  return_trajectory: bool, cancel_flag: Optional[C.c_int]) -> SampleResult:
+                  return_trajectory: bool, cancel_flag: Optional[C.c_int],
+                  save_indices: Optional[Sequence[int]] = None) -> SampleResult:
     lib = _lib.load()
     dev = x_T.device
     B, Cc, H, W = x_T.shape
@@ -266,11 +307,13 @@ def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch
     bounds = segment_bounds(T, ns.seg, B * Cc * H * W)
     counts = [int(needs[a:b].sum()) for a, b in zip(bounds[:-1], bounds[1:])]
     x = x_T.to(torch.float32).contiguous().clone()
-    traj = torch.empty((T, B, Cc, H, W), dtype=torch.float32, device=dev) if return_trajectory else None
+    kept, rows = _frame_rows(T, return_trajectory, save_indices)
+    if return_trajectory and rows is None:
+        rows = np.arange(T, dtype=np.int32)                     # a segment's steps go to their rows of the whole run
+    traj = torch.empty((len(kept), B, Cc, H, W), dtype=torch.float32, device=dev) if return_trajectory else None
     out_u8 = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=dev)
     clip = scheduler.config.clip_sample_range if scheduler.config.clip_sample else 0.0
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    n_elem = B * Cc * H * W
     done_total, rc = 0, 0
     ns.prefetch(0, counts[0])
     for k, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
@@ -280,13 +323,15 @@ def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch
             ns.prefetch(slot ^ 1, counts[k + 1])                # drawn while the GPU runs this segment
         done = C.c_int(0)
         last = b == T
-        rc = lib.sisic_sample(model.handle, x.data_ptr(), B, H, W, b - a,
-                              C.cast(ts[a:b].contiguous().data_ptr(), _lib.c_int64_p),
-                              C.cast(coef[a:b].contiguous().data_ptr(), _lib.c_float_p), float(clip),
-                              z.data_ptr() if z is not None else None,
-                              traj.data_ptr() + a * n_elem * 4 if traj is not None else None,
-                              out_u8.data_ptr() if last else None,
-                              C.byref(cancel_flag) if cancel_flag is not None else None, C.byref(done), stream)
+        seg_rows = np.ascontiguousarray(rows[a:b]) if traj is not None and len(kept) else None
+        rc = lib.sisic_sample_frames(model.handle, x.data_ptr(), B, H, W, b - a,
+                                     C.cast(ts[a:b].contiguous().data_ptr(), _lib.c_int64_p),
+                                     C.cast(coef[a:b].contiguous().data_ptr(), _lib.c_float_p), float(clip),
+                                     z.data_ptr() if z is not None else None,
+                                     traj.data_ptr() if seg_rows is not None else None,
+                                     seg_rows.ctypes.data_as(C.POINTER(C.c_int)) if seg_rows is not None else None,
+                                     out_u8.data_ptr() if last else None,
+                                     C.byref(cancel_flag) if cancel_flag is not None else None, C.byref(done), stream)
         ns.release(slot)
         done_total += done.value
         if rc != 0:
@@ -296,7 +341,7 @@ def _run_streamed(model: HipUNet2DModel, scheduler: HipDDPMScheduler, x_T: torch
     cancelled = rc == _lib.SISIC_ECANCEL
     if cancelled:
         out_u8.zero_()
-    return SampleResult(images=out_u8, latents=x, trajectory=traj, timesteps=[int(t) for t in ts],
+    return SampleResult(images=out_u8, latents=x, trajectory=traj, trajectory_steps=kept, timesteps=[int(t) for t in ts],
                         steps_done=done_total, cancelled=cancelled)
 
 
@@ -339,9 +384,23 @@ class Sampler:
         self.latency_mode = bool(latency_mode)
         self.models: Dict[str, HipUNet2DModel] = {}
         self.cancel = C.c_int(0)          # cooperative stop flag (image_generator.py:320,396)
+        self.last_trajectory_steps: List[int] = []   # step indices of the frames the last generate(..., return_trajectory=True) kept
         self.noise_segment_steps = 64     # steps of noise drawn and uploaded per pipeline stage (NoiseStream)
         self.color_statistics: Dict[str, dict] = {}   # class -> color_statistics.json entry (image_generator.py:142-170)
         self._noise_buffers: dict = {}    # pinned/device staging buffers of the last noise shape (NoiseStream)
+
+    def close(self) -> None:
+        """Shut the noise producers' thread pool down and drop the pinned / device staging buffers (the models stay)."""
+        pool = self._noise_buffers.pop("pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+        self._noise_buffers.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:              # interpreter shutdown: the executor module may already be gone
+            pass
 
     def load_color_statistics(self, path: str) -> int:
         """``checkpoints/color_statistics.json`` (image_generator.py:142-170); returns the number of classes read.
@@ -381,11 +440,16 @@ class Sampler:
         return self.generate_seeds(class_name, seeds, T, **kwargs)
 
     def generate_seeds(self, class_name: str, seeds: Sequence[int], T: int, size: Tuple[int, int] = (128, 128),
-                       return_trajectory: bool = False) -> SampleResult:
+                       return_trajectory: bool = False, save_every_n: Optional[int] = None) -> SampleResult:
+        """save_every_n: keep only the trajectory frames the reference's XAI run keeps (``trajectory_save_indices``,
+        xai/XAI.py:751-777) instead of all T -- 3.1 GB at 64 images x 64x64 x T = 1000 otherwise."""
         if class_name not in self.models:
             raise KeyError(f"no model loaded for class '{class_name}'")
         model = self.models[class_name]
         sched = self.create_scheduler(T)
+        save_indices = None
+        if return_trajectory and save_every_n is not None:
+            save_indices = trajectory_save_indices([int(t) for t in sched.timesteps], save_every_n)
         n_noise = sum(1 for t in sched.timesteps if int(t) > 0)
         H, W = size
         # noise is drawn segment by segment on worker threads while the GPU samples (NoiseStream); the values are
@@ -395,7 +459,7 @@ class Sampler:
         try:
             hashes = [noise_hash(ns.x_T[b:b + 1]) for b in range(len(seeds))]
             res = run_sampling_loop(model, sched, ns.x_T.to(self.device), ns if n_noise else None,
-                                    return_trajectory=return_trajectory, cancel_flag=self.cancel)
+                                    return_trajectory=return_trajectory, save_indices=save_indices, cancel_flag=self.cancel)
             torch.cuda.current_stream(self.device).synchronize()
         finally:
             ns.close()
@@ -404,8 +468,12 @@ class Sampler:
         return res
 
     def generate(self, seed: int, class_name: str, T: int, *, count: int = 1, size: Tuple[int, int] = (128, 128),
-                 return_trajectory: bool = False, seed_is_base: bool = False, postprocess: bool = False):
+                 return_trajectory: bool = False, seed_is_base: bool = False, postprocess: bool = False,
+                 save_every_n: Optional[int] = None):
         """``generate(seed, class, T)``: returns (uint8 [count,H,W,3] numpy, trajectory list | None).
+
+        save_every_n: with return_trajectory, the list holds only the frames of ``trajectory_save_indices`` (every n-th
+        step and the last: xai/XAI.py:751-757), in step order; ``last_trajectory_steps`` then names their step indices.
 
         seed_is_base=False: image i uses ``manual_seed(seed + i)`` directly (the literal call);
         seed_is_base=True: ``seed`` is the GUI's base seed and image i uses
@@ -418,11 +486,14 @@ class Sampler:
             seeds = [image_seed(seed, class_name, i) for i in range(count)]
         else:
             seeds = [(int(seed) + i) & 0x7FFFFFFF for i in range(count)]
-        res = self.generate_images(class_name, seeds, T, size=size, return_trajectory=return_trajectory)
+        res = self.generate_images(class_name, seeds, T, size=size, return_trajectory=return_trajectory,
+                                   save_every_n=save_every_n)
+        self.last_trajectory_steps = list(res.trajectory_steps)
+        n_frames = sum(1 for i in res.trajectory_steps if i < res.steps_done)       # kept frames of the completed steps
         if res.cancelled:
             # the reference returns False for a stopped image (image_generator.py:396-398); the tuple shape is kept, with
             # no images, and the steps that did complete when a trajectory was asked for
-            traj = [res.trajectory[i] for i in range(res.steps_done)] if return_trajectory else None
+            traj = [res.trajectory[i] for i in range(n_frames)] if return_trajectory else None
             return None, traj
         images = res.images.cpu().numpy()
         if postprocess:
@@ -430,7 +501,7 @@ class Sampler:
         traj = None
         if return_trajectory:
             # list of per-step (B,3,H,W) tensors, the shape xai_integration.py consumes
-            traj = [res.trajectory[i] for i in range(res.steps_done)]
+            traj = [res.trajectory[i] for i in range(n_frames)]
         return images, traj
 
 

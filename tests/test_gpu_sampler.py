@@ -346,3 +346,41 @@ def test_T1000_chain_at_the_headline_resolutions(sampler, golden_dir, name, size
         with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
             f.write(f"{max(worst, end):.3e}\t1.0e-02\tT=1000 chain {size}x{size} seed {seed}: worst kept frame / end; uint8 within 1 LSB {frac:.5f}\n")
     assert frac >= 0.99
+
+
+def test_trajectory_stride_keeps_the_same_frames(synthetic_sd):
+    """VERDICT r03 item 7 (xai/XAI.py:751-757 `save_indices`): with save_every_n the trajectory holds every n-th step and the
+    last one only, and those frames are bit-equal to the same frames of the all-frames run -- launch-by-launch loop,
+    graph-replayed loop, segmented noise stream and the generate() call surface."""
+    from synt_isic_amd.sampler import Sampler, draw_noise, run_sampling_loop, trajectory_save_indices
+    plain, graph = Sampler(DEV), Sampler(DEV)
+    plain.add_model("NV", synthetic_sd).set_graph_mode(0)
+    graph.add_model("NV", synthetic_sd).set_graph_mode(1)
+    seeds, T = [3, 4], 13
+    full = plain.generate_seeds("NV", seeds, T, (32, 32), return_trajectory=True)
+    assert full.trajectory.shape[0] == T and full.trajectory_steps == list(range(T))
+    for every in (1, 4, 5, 12, 13):
+        keep = trajectory_save_indices(full.timesteps, every)
+        for s in (plain, graph):
+            for seg in (64, 5):                                      # one sisic_sample_frames call, or three
+                s.noise_segment_steps = seg
+                r = s.generate_seeds("NV", seeds, T, (32, 32), return_trajectory=True, save_every_n=every)
+                assert r.trajectory_steps == keep and r.trajectory.shape == (len(keep), 2, 3, 32, 32)
+                assert torch.equal(r.trajectory, full.trajectory[keep]), (every, seg)
+                assert torch.equal(r.latents, full.latents) and torch.equal(r.images, full.images)
+    plain.noise_segment_steps = graph.noise_segment_steps = 64
+    keep = trajectory_save_indices(full.timesteps, 4)
+    assert keep == [0, 4, 8, 12]
+    # resident noise + explicit indices (run_sampling_loop), and a list that is not sorted
+    sched = plain.create_scheduler(T)
+    x_T, z = draw_noise(seeds, T - 1, (3, 32, 32))
+    r = run_sampling_loop(plain.models["NV"], sched, x_T.to(DEV), z.to(DEV), return_trajectory=True, save_indices=[12, 2, 7, 2])
+    assert r.trajectory_steps == [2, 7, 12] and torch.equal(r.trajectory, full.trajectory[[2, 7, 12]])
+    with pytest.raises(ValueError):
+        run_sampling_loop(plain.models["NV"], sched, x_T.to(DEV), z.to(DEV), return_trajectory=True, save_indices=[13])
+    # the call surface: a list of the kept frames, their step indices beside it
+    images, traj = plain.generate(3, "NV", T, count=2, size=(32, 32), return_trajectory=True, save_every_n=4)
+    assert len(traj) == 4 and plain.last_trajectory_steps == [0, 4, 8, 12]
+    assert torch.equal(traj[-1], full.latents) and np.array_equal(images, full.images.cpu().numpy())
+    plain.close()
+    graph.close()

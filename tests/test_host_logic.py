@@ -294,3 +294,46 @@ def test_streamed_segments_cover_the_run_and_ramp_when_a_segment_is_a_lot_of_rng
     assert segment_bounds(50, 64, 3 * 64 * 64) == [0, 50]
     assert segment_bounds(130, 64, 3 * 64 * 64) == [0, 64, 128, 130]
 
+
+
+def _reference_save_indices(timesteps, save_every):
+    """xai/XAI.py:751-777 and :815-822 restated step by step as that function runs (the set built before the loop, then the
+    per-step test inside it) -- the test's own statement of the reference's behaviour"""
+    n = len(timesteps)
+    save_indices = set(range(0, n, save_every))
+    if (n - 1) not in save_indices:
+        save_indices.add(n - 1)
+    by_t = save_every >= n
+    if by_t:
+        t_list = [int(float(t)) for t in timesteps]
+        desired = {0, max(t_list)}
+        k = 0
+        while k <= 1000:
+            desired.add(k)
+            k += max(1, int(save_every))
+        for dt in desired:
+            save_indices.add(min(range(len(t_list)), key=lambda i: abs(t_list[i] - dt)))
+    kept = []
+    for i, t in enumerate(timesteps):
+        save = i in save_indices
+        if not save and by_t:
+            t_int = int(float(t))
+            save = (t_int % max(1, save_every) == 0) or t_int == 0
+        if save:
+            kept.append(i)
+    return kept
+
+
+def test_trajectory_save_indices_follow_the_reference():
+    from synt_isic_amd.sampler import trajectory_save_indices
+    from synt_isic_amd.scheduler import HipDDPMScheduler
+    for T in (1, 2, 13, 50, 100, 1000):
+        s = HipDDPMScheduler()
+        s.set_timesteps(T)
+        ts = [int(t) for t in s.timesteps]
+        for every in (1, 2, 5, 10, 49, 50, 100, 250, 1000):
+            assert trajectory_save_indices(ts, every) == _reference_save_indices(ts, every), (T, every)
+    assert trajectory_save_indices(list(range(980, -1, -20)), 10) == [0, 10, 20, 30, 40, 49]       # 50 steps, every 10th + the last
+    import pytest
+    with pytest.raises(ValueError):
+        trajectory_save_indices([3, 2, 1], 0)
