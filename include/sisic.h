@@ -81,7 +81,10 @@ typedef struct sisic_conv_args {
     int gn_silu;
     const float* chan_bias; /* dev [B,Cout] or NULL                       */
     int chan_bias_stride;   /* floats between samples of chan_bias; 0 = one row shared by all samples */
-    const float* residual;  /* dev [B,Cout,Hout,Wout] or NULL             */
+    const float* residual;  /* dev [B,Cout,Hout,Wout] or NULL; MAY BE `out` itself (in-place accumulate, out += conv(...)):
+                             * every kernel reads a residual element in the thread that stores that element, before the
+                             * store (tests/test_gpu_kernels.py::test_conv_residual_may_alias_out).  No other argument
+                             * may overlap `out`.                         */
     int relu;               /* 1: max(0, .) after everything (classifier) */
     float* out;             /* dev [B,Cout,Hout,Wout]                     */
     int tile_cfg;           /* 0 = auto; >0 forces a tile configuration (tests/tuning) */

@@ -785,8 +785,8 @@ template <int KSPLIT>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int planes, int HW,
                                                             int Cout, const float* __restrict__ bias,
                                                             const float* __restrict__ chan_bias, int chan_bias_stride,
-                                                            const float* __restrict__ residual, int relu,
-                                                            float* __restrict__ out, float* __restrict__ stats) {
+                                                            const float* residual, int relu,     // (out may alias residual: sisic.h)
+                                                            float* out, float* __restrict__ stats) {
     const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (plane >= planes) return;
@@ -839,8 +839,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // bit for bit; the GroupNorm partials are summed over another tree (four values per lane, then a 16-lane butterfly).
 __global__ void __launch_bounds__(256) splitk_reduce64_kernel(const float4* __restrict__ part, int planes, int Cout,
                                                               const float* __restrict__ bias, const float* __restrict__ chan_bias,
-                                                              int chan_bias_stride, const float4* __restrict__ residual, int relu,
-                                                              float4* __restrict__ out, float4* __restrict__ stats) {
+                                                              int chan_bias_stride, const float4* residual, int relu,   // (out may alias residual)
+                                                              float4* out, float4* __restrict__ stats) {
     const int plane_raw = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
     const bool valid = plane_raw < planes;               // (a row without a plane runs along on plane 0: the butterflies need every lane)
     const int plane = valid ? plane_raw : 0;
@@ -881,8 +881,8 @@ __global__ void __launch_bounds__(256) splitk_reduce64_kernel(const float4* __re
 __global__ void __launch_bounds__(256) splitk_reduce_plane_kernel(const float* __restrict__ part, int ksplit, int planes, int HW,
                                                                   int segs, int Cout, const float* __restrict__ bias,
                                                                   const float* __restrict__ chan_bias, int chan_bias_stride,
-                                                                  const float* __restrict__ residual, int relu,
-                                                                  float* __restrict__ out, float* __restrict__ stats) {
+                                                                  const float* residual, int relu,      // (out may alias residual)
+                                                                  float* out, float* __restrict__ stats) {
     __shared__ float red[8];
     const int plane = blockIdx.x / segs, seg = blockIdx.x % segs;
     const int b = plane / Cout, co = plane % Cout;

@@ -72,10 +72,10 @@ def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bias=None, x2=None, stride=1,
            upsample=False, gn_scale=None, gn_shift=None, gn_silu=False, chan_bias=None, residual=None,
-           relu=False, tile_cfg=0, w_winograd=None, with_stats=False):
+           relu=False, tile_cfg=0, w_winograd=None, with_stats=False, out=None):
     """sisic_conv2d.  with_stats=True also returns the GroupNorm partials the epilogue wrote, as a
     [B, Cout, slots, 4] tensor of (count, sum, centred M2, 0), or None when this launch cannot produce them
-    (sisic_conv_stats_slots() == 0)."""
+    (sisic_conv_stats_slots() == 0).  ``out``: the output tensor to write (it may be ``residual`` itself: include/sisic.h)."""
     lib = _lib.load()
     B, c0, H, W = x.shape
     c1 = 0 if x2 is None else x2.shape[1]
@@ -83,7 +83,10 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bi
     pad = ksize // 2
     Ho = (Hc + 2 * pad - ksize) // stride + 1
     Wo = (Wc + 2 * pad - ksize) // stride + 1
-    out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, cout, Ho, Wo) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError(f"out must be a contiguous fp32 {(B, cout, Ho, Wo)} tensor on {x.device}")
     a = ConvArgs()
     a.in0 = _ptr(x, "x"); a.in1 = _ptr(x2, "x2"); a.c0 = c0; a.c1 = c1
     a.B = B; a.Hin = H; a.Win = W

@@ -537,6 +537,79 @@ def test_bf16x3_kernels_every_loop_tail(cin):
                what=f"bf16x3 pointwise cfg{cfg} {cin} channels")
 
 
+def _rel_close(got, ref64, what):
+    """the bf16x3 bound WITHOUT the max(1, .) floor: error relative to the largest reference output, whatever its magnitude"""
+    got = got.detach().cpu().double()
+    top = ref64.abs().max().item()
+    err = (got - ref64).abs().max().item()
+    if os.environ.get("SISIC_TEST_ERRLOG"):
+        with open(os.environ["SISIC_TEST_ERRLOG"], "a") as f:
+            f.write(f"{err / top:.3e}\t{KTOL:.1e}\t{what}\n")
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    assert err <= KTOL * top, f"{what}: max abs err {err:.3e} > {KTOL} * {top:.3e}"
+
+
+BF3_CASES = [(74, 3, 2, 32, 32, 72, 64),      # (tile_cfg, ksize, B, H, W, Cin, Cout): Winograd, 16x16-pixel tiles
+             (92, 3, 4, 8, 8, 128, 64),       # the 8x8 level: four images per workgroup, channels split four ways
+             (28, 1, 2, 16, 16, 136, 128)]    # pointwise
+
+
+def _bf3_run(cfg, k, x, w, **kw):
+    return _run_wino(x, w, cfg, **kw) if k == 3 else _run_conv(x, w, cfg, **kw)
+
+
+@pytest.mark.parametrize("cfg,k,B,H,W,cin,cout", BF3_CASES)
+def test_bf16x3_scale_sweep(cfg, k, B, H, W, cin, cout):
+    """the domain of the "fp32-equivalent" bf16x3 kernels.  A bf16 term keeps fp32's exponent, so the exact
+    three-term split holds at every magnitude: inputs and weights scaled by 1e-6 ... 1e4 (products from 1e-12 to 1e8 of the
+    O(1) case) and magnitudes mixed over eight decades INSIDE one reduction meet the same bound as the O(1) tests -- taken
+    relative to the largest output (no max(1, .) floor)."""
+    x0 = _rand(B, cin, H, W, seed=900 + cfg)
+    w0 = _rand(cout, cin, k, k, seed=901 + cfg, scale=(k * k * cin) ** -0.5)
+    b0 = _rand(cout, seed=902 + cfg)
+    for sx, sw in itertools.product((1e-6, 1e-3, 1e3, 1e4), repeat=2):
+        x, w, b = x0 * sx, w0 * sw, b0 * (sx * sw)
+        _rel_close(_bf3_run(cfg, k, x, w, bias=b), _conv_ref(x, w, b), f"bf16x3 cfg{cfg} inputs x{sx:g} weights x{sw:g}")
+    # eight decades inside one reduction: channel c of the input carries magnitude 10^e_c, e_c uniform in [-4, 4] ...
+    g = torch.Generator().manual_seed(903 + cfg)
+    mag = 10.0 ** (8.0 * torch.rand(cin, generator=g) - 4.0)
+    xm = x0 * mag[None, :, None, None]
+    _rel_close(_bf3_run(cfg, k, xm, w0, bias=b0), _conv_ref(xm, w0, b0), f"bf16x3 cfg{cfg} channel magnitudes 1e-4..1e4")
+    # ... and with the weights carrying the inverse magnitudes, so that every channel contributes O(1)
+    wm = w0 / mag[None, :, None, None]
+    _rel_close(_bf3_run(cfg, k, xm, wm, bias=b0), _conv_ref(xm, wm, b0), f"bf16x3 cfg{cfg} compensated magnitudes")
+    # magnitudes mixed pixel by pixel (what the Winograd input transform adds together before the split)
+    pm = 10.0 ** (8.0 * torch.rand(B, 1, H, W, generator=g) - 4.0)
+    xp = x0 * pm
+    _rel_close(_bf3_run(cfg, k, xp, w0, bias=b0), _conv_ref(xp, w0, b0), f"bf16x3 cfg{cfg} pixel magnitudes 1e-4..1e4")
+
+
+@pytest.mark.parametrize("cfg,k,B,H,W,cin,cout", BF3_CASES)
+def test_bf16x3_non_finite_inputs(cfg, k, B, H, W, cin, cout):
+    """What +-Inf / NaN inputs produce against F.conv2d: the split computes x - hi, which is NaN for an
+    infinite x, so every output that fp32 arithmetic makes +-Inf or NaN is NaN here -- never a finite number -- and every
+    output that does not depend on the poisoned input keeps its bits.  That also holds for the Winograd kernels: a patch
+    element enters exactly the positions of V whose products reach the outputs with that element in their 3 x 3 window."""
+    x = _rand(B, cin, H, W, seed=910 + cfg)
+    w = _rand(cout, cin, k, k, seed=911 + cfg, scale=(k * k * cin) ** -0.5)
+    clean = _bf3_run(cfg, k, x, w).cpu()
+    for (py, px), bad in itertools.product(((5, 2), (0, 0), (H - 1, 3), (2, W - 1)), (float("inf"), float("-inf"), float("nan"))):
+        xb = x.clone()
+        xb[0, 3, py, px] = bad
+        got = _bf3_run(cfg, k, xb, w).cpu()
+        dep = ~torch.isfinite(F.conv2d(xb, w, padding=k // 2))          # the outputs fp32 arithmetic makes +-Inf / NaN
+        win = torch.zeros(B, cout, H, W, dtype=torch.bool)
+        win[0, :, max(0, py - k // 2):py + k // 2 + 1, max(0, px - k // 2):px + k // 2 + 1] = True
+        assert torch.equal(dep, win)                                    # (= the k x k window around the pixel, every channel)
+        assert torch.isnan(got[dep]).all(), f"cfg{cfg} {bad} at {(py, px)}: a non-finite reference output came out finite"
+        assert torch.equal(got[~dep], clean[~dep]), f"cfg{cfg} {bad} at {(py, px)}: an output outside the window changed"
+    # a NaN weight poisons its output channel only
+    wb = w.clone()
+    wb[7, 1, 0, 0] = float("nan")
+    got = _bf3_run(cfg, k, x, wb).cpu()
+    assert torch.isnan(got[:, 7]).all() and torch.equal(got[:, :7], clean[:, :7]) and torch.equal(got[:, 8:], clean[:, 8:])
+
+
 def test_conv1x1_pointwise_bf16x3_item_width_does_not_change_bits():
     """The kernel gives a wave 64 pixels when that still leaves every SIMD two waves, 32 otherwise -- a choice that
     depends on the batch.  An image's bits must not: the same image alone (32-pixel items) and inside a batch of 16
@@ -935,3 +1008,32 @@ def test_conv2d_auto_dispatch_fuzz():
             m2 = stc[..., 2].sum(-1) + (stc[..., 0] * (mean_i - mean[..., None]) ** 2).sum(-1)
             _close((m2 / n).float(), yc.var((2, 3), unbiased=False), tol=1e-4, what=what + " (partial M2)")
     assert len(picked) >= 8          # the draw really covered the dispatch space
+
+
+@pytest.mark.parametrize("cfg,k,ups,B,H,W,cin,cout", [
+    (20, 1, False, 2, 16, 16, 64, 64), (22, 1, False, 2, 12, 20, 40, 70), (28, 1, False, 2, 16, 16, 136, 128),
+    (0, 3, True, 2, 10, 14, 24, 40),            # the generic MFMA path with a nearest-2x input
+    (74, 3, False, 3, 32, 32, 72, 64), (92, 3, False, 5, 8, 8, 128, 64), (0, 3, False, 2, 8, 8, 64, 64), (60, 3, False, 2, 18, 10, 24, 70),
+    (4, 3, False, 2, 9, 5, 16, 64), (50, 3, False, 2, 16, 16, 20, 3), (11, 3, False, 2, 16, 16, 16, 64)])
+def test_conv_residual_may_alias_out(cfg, k, ups, B, H, W, cin, cout):
+    """the backward pass accumulates a data gradient in place (conv2d with out = residual, train.cpp).  The
+    contract (include/sisic.h): every kernel reads a residual element in the thread that stores it, before the store --
+    also the K-split reductions, whose `residual` and `out` are no longer __restrict__.  In place == out of place, bit for bit."""
+    from synt_isic_amd import ops
+    d = lambda t: None if t is None else t.to(DEV).contiguous()
+    x = _rand(B, cin, H, W, seed=950 + cfg)
+    w = _rand(cout, cin, k, k, seed=951 + cfg, scale=(k * k * cin) ** -0.5)
+    b = _rand(cout, seed=952 + cfg)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    stride = 2 if cfg == 11 else 1
+    if stride == 2:
+        Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    res = _rand(B, cout, Ho, Wo, seed=953 + cfg)
+    ww = ops.pack_winograd_weight(d(w)) if (k == 3 and stride == 1 and cout > 4) else None
+    common = dict(bias=d(b), upsample=ups, stride=stride, tile_cfg=cfg, w_winograd=ww)
+    want = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, k, residual=d(res), **common)
+    buf = d(res).clone()
+    got = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, k, residual=buf, out=buf, **common)
+    assert got.data_ptr() == buf.data_ptr()
+    assert torch.equal(got, want), f"cfg{cfg}: in-place accumulate differs from the out-of-place result"
+    _close(got, _conv_ref(x, w, b, upsample=ups, stride=stride, residual=res), what=f"in-place conv cfg{cfg}")
