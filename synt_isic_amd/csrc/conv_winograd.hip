@@ -59,6 +59,7 @@ struct WinoParams {
     const float* u;     // packed transformed filters [Cin_pad][16][cout_pad]
     const float* uw;    // the same filters in the wide form's packing (conv_winograd_wide.inc), behind the first
     const float* ur;    // the split filters in the row-per-wave kernel's packing (conv_winograd_bf3r.inc), the fourth region
+    int ur_bytes;       // ... and that region's size (its buffer descriptor is range-checked)
     int cout_pad;
     const float* bias;
     int Cout;
@@ -993,6 +994,8 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     if (cfg == 75) {                // fp32-equivalent products on the bf16 pipe, a wave per row of V (conv_winograd_bf3r.inc)
         p.ur = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1) + winograd_bf3_one_numel(a.Cout, a.c0 + a.c1);
         p.cout_pad = round_up(a.Cout, 128);
+        SISIC_REQUIRE(4.0 * (double)winograd_bf3_one_numel(a.Cout, a.c0 + a.c1) < 2147483648.0, "conv2d(winograd bf16x3 rows): filter region too large for a 31-bit byte count");
+        p.ur_bytes = (int)(4 * winograd_bf3_one_numel(a.Cout, a.c0 + a.c1));
         return launch_bf3r_pro(ctx, p, s);
     }
     if (cfg == 74) {                // fp32-equivalent products on the bf16 pipe (conv_winograd_bf3.inc)
