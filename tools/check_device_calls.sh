@@ -2,7 +2,10 @@
 # Every kernel of the library must be ONE function: a lambda that the inliner leaves as a function of its own keeps its captures
 # (accumulators!) in memory -- the 7x7 instance of conv_mfma_kernel ran four times slower that way for most of round 3.  Compiles
 # every .hip to assembly and fails on an outlined lambda (_ZZN...) or a call (s_swappc).   bash tools/check_device_calls.sh
-cd "$(dirname "$0")/../synt_isic_amd/csrc" || exit 1
+# Also (round 4): tools/isa_hazard_check.py over the same assembly -- a transcendental result read by the very next vector
+# instruction, which the compiler pads itself except inside an inline-asm statement.
+here=$(cd "$(dirname "$0")" && pwd)
+cd "$here/../synt_isic_amd/csrc" || exit 1
 tmp=$(mktemp -d)
 rc=0
 for f in *.hip; do
@@ -11,6 +14,7 @@ for f in *.hip; do
     n=$(grep -c '^_ZZN' "$tmp/${f%.hip}.s"); c=$(grep -c 's_swappc' "$tmp/${f%.hip}.s")
     echo "$f: $n outlined lambdas, $c calls"
     [ "$n" -eq 0 ] && [ "$c" -eq 0 ] || rc=1
+    python3 "$here/isa_hazard_check.py" "$tmp/${f%.hip}.s" || rc=1
 done
 rm -rf "$tmp"
 exit $rc
