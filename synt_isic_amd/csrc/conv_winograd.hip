@@ -775,6 +775,7 @@ int64_t winograd_packed_numel(int Cout, int Cin) {
 #include "conv_winograd_bf3.inc"
 #include "conv_winograd_bf3r.inc"
 #include "conv_winograd_bf3p.inc"
+#include "conv_winograd_bf3h.inc"
 
 int launch_winograd_pack_bf3(sisic_ctx*, int Cout, int Cin, float* packed, hipStream_t s) {
     const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout), cout_pad128 = round_up(Cout, 128);
@@ -993,6 +994,13 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
     static const bool col_default = [] { const char* e = std::getenv("SISIC_WINO_COL"); return !e || std::atoi(e) != 0; }();
+    if (cfg == 77) {                // the bf16x3 kernel in half tiles, two workgroups per CU (conv_winograd_bf3h.inc): third region's filters
+        p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1);
+        p.cout_pad = round_up(a.Cout, 128);
+        SISIC_REQUIRE(4.0 * (double)winograd_bf3_one_numel(a.Cout, a.c0 + a.c1) < 2147483648.0, "conv2d(winograd bf16x3 half-tile): filter region too large for a 31-bit byte count");
+        p.uw_bytes = (int)(4 * winograd_bf3_one_numel(a.Cout, a.c0 + a.c1));
+        return launch_bf3h_pro(ctx, p, s);
+    }
     if (cfg == 76) {                // the bf16x3 kernel with a pipelined channel loop (conv_winograd_bf3p.inc): third region's filters
         p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1);
         p.cout_pad = round_up(a.Cout, 128);

@@ -111,7 +111,7 @@ def main():
             def run():
                 return ops.conv2d(x, wp, cout, k, bias=bias, x2=x2, stride=stride, upsample=bool(ups),
                                   gn_scale=gs, gn_shift=gb, gn_silu=(gn == 1), residual=r, tile_cfg=cfg,
-                                  w_winograd=wino if (cfg == 0 or 60 <= cfg <= 76 or cfg in (78, 79, 90, 91, 92)) else None)
+                                  w_winograd=wino if (cfg == 0 or 60 <= cfg <= 79 or cfg in (90, 91, 92)) else None)
             try:
                 run()
             except Exception as e:  # cfg not applicable
