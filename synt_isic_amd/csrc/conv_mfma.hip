@@ -491,7 +491,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
 // there are 32-bit).  Returns the tile configuration, 0 = not Winograd.
 static int winograd_cfg(const sisic_conv_args& a) {
     if (!(a.ksize == 3 && a.stride == 1 && a.w_winograd != nullptr && a.Cout > 4) || a.upsample == 2) return 0;
-    if ((a.tile_cfg >= 60 && a.tile_cfg <= 77) || a.tile_cfg == 78 || a.tile_cfg == 79 || (a.tile_cfg >= 90 && a.tile_cfg <= 92)) return a.tile_cfg;
+    if ((a.tile_cfg >= 60 && a.tile_cfg <= 74) || a.tile_cfg == 78 || a.tile_cfg == 79 || (a.tile_cfg >= 90 && a.tile_cfg <= 92)) return a.tile_cfg;
     if (a.tile_cfg != 0) return 0;
     const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
     const bool fits32 = 16.0 * std::max(a.c0, a.c1) * a.Hin * a.Win < 4294967296.0;
@@ -543,7 +543,7 @@ int conv_stats_slots(const sisic_conv_args& a) {
         if (cfg >= 90 && cfg <= 92) return 1;
         const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
         if ((cfg == 78 || cfg == 79) && wino_latency_ksplit(a.Cout, a.c0 + a.c1, Hout, Wout) > 1) return wino_latency_segments(Hout, Wout);   // from the plane reduction
-        if ((cfg >= 68 && cfg <= 73) || cfg == 77 || cfg == 78 || cfg == 79) return ((Hout + 7) / 8) * ((Wout + 15) / 16);   // 8 x 16 output pixels per workgroup
+        if ((cfg >= 68 && cfg <= 73) || cfg == 78 || cfg == 79) return ((Hout + 7) / 8) * ((Wout + 15) / 16);   // 8 x 16 output pixels per workgroup
         const int edge = (cfg == 61 || cfg == 63 || cfg == 65 || cfg == 67) ? 8 : 16;
         return ((Hout + edge - 1) / edge) * ((Wout + edge - 1) / edge);
     }
@@ -597,7 +597,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
     const bool wino_ups9 = use_wino && a.upsample && !a.gn_scale && winograd_cfg(a) == 66;
     ProfileScope prof(slots_query ? nullptr : ctx, s, a.ksize == 1 ? PK_CONV1 : PK_CONV3, bytes, flops,
                       use_wino ? flops * (wino_ups9 ? 9.0 : 16.0) / 36.0 : flops,
-                      (use_wino && winograd_cfg(a) >= 74 && winograd_cfg(a) <= 77) ? PK_WINO_BF3 :
+                      (use_wino && winograd_cfg(a) == 74) ? PK_WINO_BF3 :
                       (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || (winograd_cfg(a) >= 68 && winograd_cfg(a) <= 73) || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
 
     if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50 || cfg == 51)) {
@@ -610,7 +610,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         SISIC_REQUIRE(!slots_query, "conv2d: internal: slot query on the Winograd path");
         return launch_conv_winograd(ctx, a, a.w_winograd, winograd_cfg(a), s);
     }
-    SISIC_REQUIRE((cfg < 60 || cfg > 77) && cfg != 78 && cfg != 79 && (cfg < 90 || cfg > 92), "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
+    SISIC_REQUIRE((cfg < 60 || cfg > 74) && cfg != 78 && cfg != 79 && (cfg < 90 || cfg > 92), "conv2d: tile_cfg %d needs w_winograd, ksize 3 and stride 1", cfg);
     if (a.ksize == 7) {
         if (cfg == 0) cfg = 41;
         if (cfg == 41) return launch_cfg<7, 2, 2, 1, 1, 4, 32, 2>(ctx, p, s);   // 2-channel chunks: 4 spill 256 B/lane (13 weight float4 + 15 halo elements per thread)

@@ -58,9 +58,6 @@ struct WinoParams {
     int ups;
     const float* u;     // packed transformed filters [Cin_pad][16][cout_pad]
     const float* uw;    // the same filters in the wide form's packing (conv_winograd_wide.inc), behind the first
-    const float* ur;    // the split filters in the row-per-wave kernel's packing (conv_winograd_bf3r.inc), the fourth region
-    int ur_bytes;       // ... and that region's size (its buffer descriptor is range-checked)
-    int uw_bytes;       // size of the region uw points at, where the kernel range-checks it (conv_winograd_bf3p.inc)
     int cout_pad;
     const float* bias;
     int Cout;
@@ -763,9 +760,7 @@ int launch_winograd_pack(sisic_ctx*, const float* w, int Cout, int Cin, float* p
 }
 
 // third region: the split filters of the bf16x3 form (conv_winograd_bf3.inc): three bf16 terms = 1.5 dwords per filter value
-// (and a fourth of the same size: the same terms in the row-per-wave kernel's operand order, conv_winograd_bf3r.inc)
-static int64_t winograd_bf3_one_numel(int Cout, int Cin) { return winograd_wide_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin) / 2; }
-static int64_t winograd_bf3_numel(int Cout, int Cin) { return 2 * winograd_bf3_one_numel(Cout, Cin); }
+static int64_t winograd_bf3_numel(int Cout, int Cin) { return winograd_wide_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin) / 2; }
 int64_t winograd_packed_numel(int Cout, int Cin) {
     return winograd_first_numel(Cout, Cin) + winograd_wide_numel(Cout, Cin) + winograd_bf3_numel(Cout, Cin);
 }
@@ -773,9 +768,6 @@ int64_t winograd_packed_numel(int Cout, int Cin) {
 #include "conv_winograd_wide.inc"
 #include "conv_winograd_col.inc"
 #include "conv_winograd_bf3.inc"
-#include "conv_winograd_bf3r.inc"
-#include "conv_winograd_bf3p.inc"
-#include "conv_winograd_bf3h.inc"
 
 int launch_winograd_pack_bf3(sisic_ctx*, int Cout, int Cin, float* packed, hipStream_t s) {
     const int cin_pad = round_up(Cin, 16), cout_pad = conv_cout_pad(Cout), cout_pad128 = round_up(Cout, 128);
@@ -994,27 +986,6 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
     static const bool col_default = [] { const char* e = std::getenv("SISIC_WINO_COL"); return !e || std::atoi(e) != 0; }();
-    if (cfg == 77) {                // the bf16x3 kernel in half tiles, two workgroups per CU (conv_winograd_bf3h.inc): third region's filters
-        p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1);
-        p.cout_pad = round_up(a.Cout, 128);
-        SISIC_REQUIRE(4.0 * (double)winograd_bf3_one_numel(a.Cout, a.c0 + a.c1) < 2147483648.0, "conv2d(winograd bf16x3 half-tile): filter region too large for a 31-bit byte count");
-        p.uw_bytes = (int)(4 * winograd_bf3_one_numel(a.Cout, a.c0 + a.c1));
-        return launch_bf3h_pro(ctx, p, s);
-    }
-    if (cfg == 76) {                // the bf16x3 kernel with a pipelined channel loop (conv_winograd_bf3p.inc): third region's filters
-        p.uw = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1);
-        p.cout_pad = round_up(a.Cout, 128);
-        SISIC_REQUIRE(4.0 * (double)winograd_bf3_one_numel(a.Cout, a.c0 + a.c1) < 2147483648.0, "conv2d(winograd bf16x3 pipelined): filter region too large for a 31-bit byte count");
-        p.uw_bytes = (int)(4 * winograd_bf3_one_numel(a.Cout, a.c0 + a.c1));
-        return launch_bf3p_pro(ctx, p, s);
-    }
-    if (cfg == 75) {                // fp32-equivalent products on the bf16 pipe, a wave per half row of V (conv_winograd_bf3r.inc)
-        p.ur = u_packed + winograd_first_numel(a.Cout, a.c0 + a.c1) + winograd_wide_numel(a.Cout, a.c0 + a.c1) + winograd_bf3_one_numel(a.Cout, a.c0 + a.c1);
-        p.cout_pad = round_up(a.Cout, 128);
-        SISIC_REQUIRE(4.0 * (double)winograd_bf3_one_numel(a.Cout, a.c0 + a.c1) < 2147483648.0, "conv2d(winograd bf16x3 rows): filter region too large for a 31-bit byte count");
-        p.ur_bytes = (int)(4 * winograd_bf3_one_numel(a.Cout, a.c0 + a.c1));
-        return launch_bf3r_pro(ctx, p, s);
-    }
     if (cfg == 74) {                // fp32-equivalent products on the bf16 pipe (conv_winograd_bf3.inc)
         // (a nearest-2x input is read through the staging plan's addresses: all 16 positions are multiplied, where the f32
         //  upsample form multiplies 9 -- which of the two is faster depends on the plane, conv_mfma.hip)

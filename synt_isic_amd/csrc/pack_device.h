@@ -107,35 +107,8 @@ __device__ __forceinline__ void winograd_pack_wide_elem(size_t i, const float* _
 // then U_lo of block 0 [64 lanes][2] and of block 1.  Lane (co = lane & 31, g = lane >> 5) of a block carries input channels
 // 4 g .. 4 g + 3 of the chunk; a term's two dwords are channels (1 : 0) and (3 : 2) of the group
 __device__ __forceinline__ void winograd_pack_bf3_elem(size_t i, const float* __restrict__ u_first, int cout_pad, int cout_pad128,
-                                                       unsigned* __restrict__ out, size_t first_total) {
+                                                       unsigned* __restrict__ out) {
     const int n_co64 = cout_pad128 >> 6;
-    if (i >= first_total) {
-        // fourth region, the row-per-wave kernel's packing (conv_winograd_bf3r.inc): [chunk][64-channel tile][position][piece 0..2]
-        // [lane][4]; a lane's twelve dwords = [lo hi mid] of 32-channel block 0, then of block 1
-        const size_t k = i - first_total;
-        const int d = (int)(k & 3), ln = (int)((k >> 2) & 63);
-        size_t r = k >> 8;
-        const int piece = (int)(r % 3); r /= 3;
-        const int pos = (int)(r % 16); r /= 16;
-        const int tile = (int)(r % n_co64);
-        const int chunk = (int)(r / n_co64);
-        const int idx12 = 4 * piece + d, blk = idx12 / 6, t6 = idx12 % 6, tsel = t6 >> 1, pair = t6 & 1;      // tsel: 0 lo, 1 hi, 2 mid
-        const int co = 64 * tile + 32 * blk + (ln & 31), g = ln >> 5;
-        unsigned pk = 0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int ci = 8 * chunk + 4 * g + 2 * pair + e;
-            const float v = co < cout_pad ? u_first[((size_t)ci * 16 + pos) * cout_pad + co] : 0.0f;
-            const unsigned hi = __float_as_uint(v) & 0xffff0000u;
-            const float r1 = v - __uint_as_float(hi);
-            const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(mid);
-            const unsigned t = tsel == 1 ? hi : (tsel == 2 ? mid : __float_as_uint(r2));
-            pk |= (t >> 16) << (16 * e);
-        }
-        out[i] = pk;
-        return;
-    }
     const int w = (int)(i % 768);
     size_t r = i / 768;
     const int tile = (int)(r % n_co64); r /= n_co64;

@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(PB_THREADS) pack_batch_kernel(const PackJob* _
             case PackJob::CONV_PACK: conv_pack_elem(i, j.src, j.a, j.b, j.c, j.d, j.e, j.dst); break;
             case PackJob::WINO_FIRST: winograd_pack_elem(i, j.src, j.a, j.b, j.d, j.e, j.dst); break;
             case PackJob::WINO_WIDE: winograd_pack_wide_elem(i, j.src, j.a, j.b, j.dst); break;
-            case PackJob::WINO_BF3: winograd_pack_bf3_elem(i, j.src, j.a, j.b, reinterpret_cast<unsigned*>(j.dst), j.total / 2); break;
+            case PackJob::WINO_BF3: winograd_pack_bf3_elem(i, j.src, j.a, j.b, reinterpret_cast<unsigned*>(j.dst)); break;
         }
     }
 }
@@ -81,7 +81,7 @@ PackJob pack_job_wino_bf3(int Cout, int Cin, float* packed) {           // reads
     PackJob j{}; j.kind = PackJob::WINO_BF3; j.src = packed;
     const size_t wide = (size_t)round_up(Cin, 16) * 16 * round_up(Cout, 128);
     j.dst = packed + winograd_first_floats(Cout, Cin) + wide;
-    j.a = conv_cout_pad(Cout); j.b = round_up(Cout, 128); j.total = 2 * (wide + wide / 2); return j;     // third region + the row-per-wave kernel's fourth
+    j.a = conv_cout_pad(Cout); j.b = round_up(Cout, 128); j.total = wide + wide / 2; return j;
 }
 
 }  // namespace sisic

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Which part of a kernel costs what: diagnostic builds of conv_winograd.hip with parts of a loop compiled out (a -D<MACRO>=<bits>
-# per build: BF3_VAR for conv_winograd_bf3.inc, BF3R_VAR for conv_winograd_bf3r.inc; the bits are listed beside the macro's
+# per build: e.g. BF3_VAR (bits) or BF3_ONE_UA (0 / 1) for conv_winograd_bf3.inc; the values are listed beside the macro's
 # #ifndef), timed per layer with tools/conv_bench.py.  Results of these builds are WRONG: timing only, never shipped.
-#   build (here, no GPU):  bash tools/kernel_variants.sh build BF3R_VAR "0 1 2 4 8 16 32"
-#   run (GPU box):         bash tools/kernel_variants.sh run BF3R_VAR "0 1 2 4 8 16 32" 75 "64->64 @64 gn+res"   -> gpurun_out/variants_BF3R_VAR.txt
+#   build (here, no GPU):  bash tools/kernel_variants.sh build BF3_VAR "0 1 2 4 8 16 32"
+#   run (GPU box):         bash tools/kernel_variants.sh run BF3_VAR "0 1 2 4 8 16 32" 74 "64->64 @64 gn+res"   -> gpurun_out/variants_BF3_VAR.txt
 # (replaces round 3's one-off tools/r03_ab*.sh / r03_bf3_var.sh)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
