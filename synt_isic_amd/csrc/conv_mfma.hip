@@ -633,7 +633,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
         // 64-pixel x 64-channel tiles -- unless SISIC_POINTWISE_BF16X3=0.  (Shape conditions only: an image's bits must not
         // depend on the batch it is in.)
         static const bool pwb_on = [] { const char* e = std::getenv("SISIC_POINTWISE_BF16X3"); return !e || std::atoi(e) != 0; }();
-        if ((cfg == 0 && pwb_on && conv_pointwise_bf3_applicable(a)) || (cfg >= 28 && cfg <= 30)) {
+        if ((cfg == 0 && pwb_on && conv_pointwise_bf3_applicable(a)) || (cfg >= 28 && cfg <= 30) || cfg == 34 || cfg == 35) {
             if (slots_query) { *slots_query = conv_pointwise_stats_slots(a); return SISIC_OK; }
             return launch_conv_pointwise_bf3(ctx, a, s);
         }

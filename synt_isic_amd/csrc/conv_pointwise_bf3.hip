@@ -341,6 +341,426 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
     }
 }
 
+// ---- K-SPLIT form (round 4; tile_cfg 35): the small levels' 1x1 layers (256 -> 256 at 16x16: 2048 wave items of 32 pixels x 64
+// channels at batch 64, two per SIMD) are LATENCY-bound -- a wave is parked at s_waitcnt 60 % of its life (profiles/r04/
+// sol_pointwise.txt), every one of its 32 chunks waits for its own loads.  Here the four waves of a workgroup share ONE item and
+// split its input channels four ways (a quarter of the chain each, all in flight together), put their partial accumulators into
+// LDS, and each wave sums -- in the fixed order ((k0 + k1) + k2) + k3 -- and stores a quarter of the item's 64 channels.
+// Another summation order than the forms above: other bits, so the choice between them is by layer SHAPE only (launcher).
+template <int PRO>
+__global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwbk_kernel(const PwbParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int item;
+    {   // XCD-aware bijective remap (conv_mfma.hip)
+        const int L = blockIdx.x, nwg = p.nwg;
+        const int xcd = L & 7, slot = L >> 3, q = nwg >> 3, r = nwg & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    int co_i = item % p.n_co_items;
+    const int t = item / p.n_co_items;
+    int px_t = t % p.n_px, b = t / p.n_px;
+    asm volatile("" : "+s"(co_i), "+s"(px_t), "+s"(b));
+    constexpr int CB = 2;
+    const int px0 = 32 * px_t, co0 = 64 * co_i;
+    const int Cin = p.c0 + p.c1, HW = p.HW;
+    const int nl = p.nchunks / PWB_WAVES, cb = wave_u * nl;         // this wave's chunks: cb .. cb + nl - 1
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0 + (size_t)b * p.c0 * HW), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in1 ? p.in1 + (size_t)b * p.c1 * HW : p.in0), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wb), 0, -1, 0x00020000);
+    const unsigned x_voff = 4u * (unsigned)((4 * half) * HW + px0 + l31);
+    const unsigned a_lane16 = 16u * (unsigned)lane, a_lane8 = 8u * (unsigned)lane;
+
+    // LDS: [4 waves][32 accumulator registers][64 lanes] partials, then a (scale, shift) table of the wave's own channels each
+    float* const P_lds = smem;
+    float* const gnL = smem + PWB_WAVES * 32 * 64 + wave_u * (2 * 8 * nl);
+    if constexpr (PRO != 0) {
+        for (int i = lane; i < 8 * nl; i += 64) {
+            gnL[2 * i] = p.gn_scale[(size_t)b * Cin + 8 * cb + i];
+            gnL[2 * i + 1] = p.gn_shift[(size_t)b * Cin + 8 * cb + i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // written and read by this wave only
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    pwb_f32x16 acc[CB];
+#pragma unroll
+    for (int x = 0; x < CB; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.0f;
+    struct XRegs { float x[4]; };
+    auto load_x = [&](int c, XRegs& r) {                            // c: absolute chunk
+        const int cc0 = 8 * c;
+        if (cc0 < p.c0) {
+            const unsigned soff = 4u * (unsigned)(cc0 * HW);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.x[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs0, x_voff, soff + 4u * (unsigned)(k * HW), 0));
+        } else {
+            const unsigned soff = 4u * (unsigned)((cc0 - p.c0) * HW);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r.x[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, x_voff, soff + 4u * (unsigned)(k * HW), 0));
+        }
+    };
+    auto load_f = [&](int c, pwb_u4 (&fa)[CB], pwb_u2 (&fl)[CB]) {
+        const unsigned s0 = 3072u * (unsigned)(c * p.n_co64 + co_i);
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+            fa[x] = __builtin_amdgcn_raw_buffer_load_b128(rsw, a_lane16, s0 + 1024u * (unsigned)x, 0);
+            fl[x] = __builtin_amdgcn_raw_buffer_load_b64(rsw, a_lane8, s0 + 2048u + 512u * (unsigned)x, 0);
+        }
+    };
+    struct Tup { pwb_u4 hm, mh, lh; };
+    auto make = [&](int cl, const XRegs& r) {                       // cl: the wave's local chunk (its GroupNorm table's index)
+        pwb_f4 g01 = {1.0f, 0.0f, 1.0f, 0.0f}, g23 = g01;
+        if constexpr (PRO != 0) {
+            const float* gp = gnL + 2 * (8 * cl + 4 * half);
+            g01 = *reinterpret_cast<const pwb_f4*>(gp);
+            g23 = *reinterpret_cast<const pwb_f4*>(gp + 4);
+        }
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float e = r.x[k];
+            if constexpr (PRO != 0) {
+                const float sc = k == 0 ? g01.x : (k == 1 ? g01.z : (k == 2 ? g23.x : g23.z));
+                const float sh = k == 0 ? g01.y : (k == 1 ? g01.w : (k == 2 ? g23.y : g23.w));
+                e = e * sc + sh;
+                if constexpr (PRO == 2) e = pwb_silu(e);
+            }
+            v[k] = e;
+        }
+        unsigned hi[2], mid[2], lo[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float v0 = v[2 * q], v1 = v[2 * q + 1];
+            const unsigned h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+            const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+            const unsigned m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+            const float l0 = r0 - __uint_as_float(m0), l1 = r1 - __uint_as_float(m1);
+            hi[q] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+            mid[q] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+            lo[q] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+        }
+        return Tup{pwb_u4{hi[0], hi[1], mid[0], mid[1]}, pwb_u4{mid[0], mid[1], hi[0], hi[1]}, pwb_u4{lo[0], lo[1], hi[0], hi[1]}};
+    };
+    auto mm = [&](const Tup& t, const pwb_u4 (&fa)[CB], const pwb_u2 (&fl)[CB]) {
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+            const pwb_u4 a_hl = {fa[x].x, fa[x].y, fl[x].x, fl[x].y};
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, fa[x]), __builtin_bit_cast(pwb_bf16x8, t.hm), acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, fa[x]), __builtin_bit_cast(pwb_bf16x8, t.mh), acc[x], 0, 0, 0);
+            acc[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, a_hl), __builtin_bit_cast(pwb_bf16x8, t.lh), acc[x], 0, 0, 0);
+        }
+    };
+    // every operand of the wave's (short) chain is requested up front where the registers allow: activations four chunks deep,
+    // filters two
+    constexpr int XD = 4;
+    XRegs xr[XD];
+    pwb_u4 ua[CB], ub[CB];
+    pwb_u2 ul[CB], um[CB];
+#pragma unroll
+    for (int i = 0; i < XD; ++i)
+        if (i < nl) load_x(cb + i, xr[i]);
+    load_f(cb, ua, ul);
+    if (nl > 1) load_f(cb + 1, ub, um);
+    for (int c = 0; c < nl; c += XD) {
+#pragma unroll
+        for (int i = 0; i < XD; ++i) {
+            if (c + i < nl) {
+                const Tup t = make(c + i, xr[i]);
+                if (c + i + XD < nl) load_x(cb + c + i + XD, xr[i]);
+                if ((i & 1) == 0) {
+                    mm(t, ua, ul);
+                    if (c + i + 2 < nl) load_f(cb + c + i + 2, ua, ul);
+                } else {
+                    mm(t, ub, um);
+                    if (c + i + 2 < nl) load_f(cb + c + i + 2, ub, um);
+                }
+            }
+        }
+    }
+
+    // ---- the four partial tiles through LDS; wave w sums and stores accumulator rows 8 (w & 1) .. + 7 of channel block w >> 1
+#pragma unroll
+    for (int x = 0; x < CB; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P_lds[((wave_u * 2 + x) * 16 + r) * 64 + lane] = acc[x][r];
+    __syncthreads();
+    const int x = wave_u >> 1, rb = 8 * (wave_u & 1);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.Cout * HW, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual + (size_t)b * p.Cout * HW : p.out), 0, -1, 0x00020000);
+    const unsigned o_voff = 4u * (unsigned)((4 * half) * HW + px0 + l31);
+    const int slots = HW / 32;
+    float add[8], res[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = rb + rr;
+        const int cs = co0 + 32 * x + 8 * (r >> 2) + (r & 3);
+        const int col = cs + 4 * half;
+        add[rr] = 0.0f;
+        if (p.bias) add[rr] += p.bias[col];
+        if (p.chan_bias) add[rr] += p.chan_bias[(size_t)b * p.chan_bias_stride + col];
+        res[rr] = 0.0f;
+        if (p.residual) res[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsr, o_voff, 4u * (unsigned)(cs * HW), 0));
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int r = rb + rr;
+        const int cs = co0 + 32 * x + 8 * (r >> 2) + (r & 3);
+        float part[PWB_WAVES];
+#pragma unroll
+        for (int k = 0; k < PWB_WAVES; ++k) part[k] = P_lds[((k * 2 + x) * 16 + r) * 64 + lane];
+        float v = ((part[0] + part[1]) + part[2]) + part[3];
+        v = v + add[rr] + res[rr];
+        if (p.relu) v = fmaxf(v, 0.0f);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rso, o_voff, 4u * (unsigned)(cs * HW), 0);
+        if (p.stats) {          // (the 32-pixel form's slot and summation tree, conv_pwb_kernel<PRO, 1>)
+            const int co = cs + 4 * half;
+            const float s1 = pwb_half_wave_sum(v);
+            const float d = v - s1 * (1.0f / 32.0f);
+            float dd;
+            asm volatile("v_mul_f32 %0, %1, %1" : "=v"(dd) : "v"(d));
+            const float q = pwb_half_wave_sum(dd);
+            if (l31 == 0)
+                reinterpret_cast<float4*>(p.stats)[((size_t)b * p.Cout + co) * slots + px_t] = make_float4(32.0f, s1, q, 0.0f);
+        }
+    }
+}
+
+// ---- STAGED form (round 4; tile_cfg 34): for a layer with many output channels (q, k, v of an attention block: 256 -> 768)
+// the kernel above splits every activation once per 64-channel item that reads it -- twelve times -- and the split (GroupNorm,
+// three terms, packing: ~15 vector instructions per element) is what its loop consists of.  Here a workgroup owns 64 pixels of
+// one image and ALL output channels: its waves (one per 64-channel item) first put the pixels' B operands -- GroupNorm applied,
+// split, packed exactly as above -- into LDS ONCE (Cin x 64 pixels x 6 bytes: 96 KB at 256 channels), then every wave runs the
+// contraction of its own channel item with operands that are two LDS reads per chunk and pixel block; filters from global memory
+// two chunks ahead as before.  The chain of MFMAs of an output is the one of the forms above: same bits.
+constexpr int PWBS_MAX_WAVES = 12;
+template <int PRO>
+__global__ void __launch_bounds__(64 * PWBS_MAX_WAVES) conv_pwbs_kernel(const PwbParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int wg;
+    {   // XCD-aware bijective remap (conv_mfma.hip)
+        const int L = blockIdx.x, nwg = p.nwg;
+        const int xcd = L & 7, slot = L >> 3, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = p.n_co_items;                                // one wave per 64-channel item
+    const int half = lane >> 5, l31 = lane & 31;
+    int px_t = wg % p.n_px, b = wg / p.n_px;
+    asm volatile("" : "+s"(px_t), "+s"(b));
+    constexpr int CB = 2, NB = 2;
+    const int co_i = wave_u;
+    const int px0 = 64 * px_t, co0 = 64 * co_i;
+    const int Cin = p.c0 + p.c1, HW = p.HW, n = p.nchunks;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in0 + (size_t)b * p.c0 * HW), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in1 ? p.in1 + (size_t)b * p.c1 * HW : p.in0), 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wb), 0, -1, 0x00020000);
+    const unsigned x_voff = 4u * (unsigned)((4 * half) * HW + px0 + NB * l31);
+    const unsigned a_lane16 = 16u * (unsigned)lane, a_lane8 = 8u * (unsigned)lane;
+
+    // LDS: [chunk][pixel block][64 lanes][(hi, mid) 4 dwords] then [chunk][pixel block][64 lanes][lo 2 dwords], then the GroupNorm table
+    unsigned* const S_hm = reinterpret_cast<unsigned*>(smem);
+    unsigned* const S_lo = S_hm + (size_t)n * NB * 64 * 4;
+    float* const gnL = reinterpret_cast<float*>(S_lo + (size_t)n * NB * 64 * 2);      // [input channel][scale, shift]
+    if constexpr (PRO != 0) {
+        for (int i = tid; i < Cin; i += 64 * nwaves) {
+            gnL[2 * i] = p.gn_scale[(size_t)b * Cin + i];
+            gnL[2 * i + 1] = p.gn_shift[(size_t)b * Cin + i];
+        }
+        __syncthreads();
+    }
+    // ---- stage: wave w splits chunks w, w + nwaves, ... (the lane mapping, GroupNorm and split of conv_pwb_kernel's `make`)
+    for (int c = wave_u; c < n; c += nwaves) {
+        pwb_f2 xr[4];
+        const int cc0 = 8 * c;
+        if (cc0 < p.c0) {
+            const unsigned soff = 4u * (unsigned)(cc0 * HW);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xr[k] = __builtin_bit_cast(pwb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs0, x_voff, soff + 4u * (unsigned)(k * HW), 0));
+        } else {
+            const unsigned soff = 4u * (unsigned)((cc0 - p.c0) * HW);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xr[k] = __builtin_bit_cast(pwb_f2, __builtin_amdgcn_raw_buffer_load_b64(rs1, x_voff, soff + 4u * (unsigned)(k * HW), 0));
+        }
+        pwb_f4 g01 = {1.0f, 0.0f, 1.0f, 0.0f}, g23 = g01;
+        if constexpr (PRO != 0) {
+            const float* gp = gnL + 2 * (8 * c + 4 * half);
+            g01 = *reinterpret_cast<const pwb_f4*>(gp);
+            g23 = *reinterpret_cast<const pwb_f4*>(gp + 4);
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float e = nb ? xr[k].y : xr[k].x;
+                if constexpr (PRO != 0) {
+                    const float sc = k == 0 ? g01.x : (k == 1 ? g01.z : (k == 2 ? g23.x : g23.z));
+                    const float sh = k == 0 ? g01.y : (k == 1 ? g01.w : (k == 2 ? g23.y : g23.w));
+                    e = e * sc + sh;
+                    if constexpr (PRO == 2) e = pwb_silu(e);
+                }
+                v[k] = e;
+            }
+            unsigned hi[2], mid[2], lo[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float v0 = v[2 * q], v1 = v[2 * q + 1];
+                const unsigned h0 = __float_as_uint(v0) & 0xffff0000u, h1 = __float_as_uint(v1) & 0xffff0000u;
+                const float r0 = v0 - __uint_as_float(h0), r1 = v1 - __uint_as_float(h1);
+                const unsigned m0 = __float_as_uint(r0) & 0xffff0000u, m1 = __float_as_uint(r1) & 0xffff0000u;
+                const float l0 = r0 - __uint_as_float(m0), l1 = r1 - __uint_as_float(m1);
+                hi[q] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+                mid[q] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+                lo[q] = __builtin_amdgcn_perm(__float_as_uint(l1), __float_as_uint(l0), 0x07060302u);
+            }
+            *reinterpret_cast<pwb_u4*>(S_hm + ((size_t)(c * NB + nb) * 64 + lane) * 4) = pwb_u4{hi[0], hi[1], mid[0], mid[1]};
+            *reinterpret_cast<pwb_u2*>(S_lo + ((size_t)(c * NB + nb) * 64 + lane) * 2) = pwb_u2{lo[0], lo[1]};
+        }
+    }
+    __syncthreads();
+
+    // ---- contract: this wave's 64 channels x the 64 pixels, filters two chunks ahead in registers
+    pwb_f32x16 acc[CB][NB];
+#pragma unroll
+    for (int x = 0; x < CB; ++x)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][nb][r] = 0.0f;
+    pwb_u4 ua[CB], ub[CB];
+    pwb_u2 ul[CB], um[CB];
+    auto load_f = [&](int c, pwb_u4 (&fa)[CB], pwb_u2 (&fl)[CB]) {
+        const unsigned s0 = 3072u * (unsigned)(c * p.n_co64 + co_i);
+#pragma unroll
+        for (int x = 0; x < CB; ++x) {
+            fa[x] = __builtin_amdgcn_raw_buffer_load_b128(rsw, a_lane16, s0 + 1024u * (unsigned)x, 0);
+            fl[x] = __builtin_amdgcn_raw_buffer_load_b64(rsw, a_lane8, s0 + 2048u + 512u * (unsigned)x, 0);
+        }
+    };
+    auto chunk = [&](int c, const pwb_u4 (&fa)[CB], const pwb_u2 (&fl)[CB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const pwb_u4 hm = *reinterpret_cast<const pwb_u4*>(S_hm + ((size_t)(c * NB + nb) * 64 + lane) * 4);
+            const pwb_u2 lo = *reinterpret_cast<const pwb_u2*>(S_lo + ((size_t)(c * NB + nb) * 64 + lane) * 2);
+            const pwb_u4 mh = {hm.z, hm.w, hm.x, hm.y}, lh = {lo.x, lo.y, hm.x, hm.y};
+#pragma unroll
+            for (int x = 0; x < CB; ++x) {
+                const pwb_u4 a_hl = {fa[x].x, fa[x].y, fl[x].x, fl[x].y};
+                acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, fa[x]), __builtin_bit_cast(pwb_bf16x8, hm), acc[x][nb], 0, 0, 0);
+                acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, fa[x]), __builtin_bit_cast(pwb_bf16x8, mh), acc[x][nb], 0, 0, 0);
+                acc[x][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pwb_bf16x8, a_hl), __builtin_bit_cast(pwb_bf16x8, lh), acc[x][nb], 0, 0, 0);
+            }
+        }
+    };
+    load_f(0, ua, ul);
+    if (n > 1) load_f(1, ub, um);
+    {
+        int c = 0;
+        for (; c + 1 < n; c += 2) {
+            chunk(c, ua, ul);
+            if (c + 2 < n) load_f(c + 2, ua, ul);
+            chunk(c + 1, ub, um);
+            if (c + 3 < n) load_f(c + 3, ub, um);
+        }
+        if (c < n) chunk(c, ua, ul);
+    }
+
+    // ---- epilogue: as conv_pwb_kernel<PRO, 2>
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)b * p.Cout * HW, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.residual ? p.residual + (size_t)b * p.Cout * HW : p.out), 0, -1, 0x00020000);
+    const unsigned o_voff = 4u * (unsigned)((4 * half) * HW + px0 + NB * l31);
+    const int slots = HW / 32;
+#pragma unroll
+    for (int x = 0; x < CB; ++x) {
+        float add[16];
+        pwb_f2 res[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cs = co0 + 32 * x + 8 * (r >> 2) + (r & 3);
+            const int col = cs + 4 * half;
+            add[r] = 0.0f;
+            if (p.bias) add[r] += p.bias[col];
+            if (p.chan_bias) add[r] += p.chan_bias[(size_t)b * p.chan_bias_stride + col];
+            res[r] = pwb_f2{0.0f, 0.0f};
+            if (p.residual) res[r] = __builtin_bit_cast(pwb_f2, __builtin_amdgcn_raw_buffer_load_b64(rsr, o_voff, 4u * (unsigned)(cs * HW), 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cs = co0 + 32 * x + 8 * (r >> 2) + (r & 3);
+            float vv[2];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                vv[nb] = acc[x][nb][r] + add[r] + (nb ? res[r].y : res[r].x);
+                if (p.relu) vv[nb] = fmaxf(vv[nb], 0.0f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(pwb_u2{__float_as_uint(vv[0]), __float_as_uint(vv[1])}, rso, o_voff, 4u * (unsigned)(cs * HW), 0);
+            if (p.stats) {
+                const int co = cs + 4 * half;
+                const float s1 = pwb_row16_sum(vv[0] + vv[1]);
+                const float mean = s1 * (1.0f / 32.0f);
+                const float d0 = vv[0] - mean, d1 = vv[1] - mean;
+                float q0, q1;
+                asm volatile("v_mul_f32 %0, %2, %2\n\tv_mul_f32 %1, %3, %3" : "=&v"(q0), "=&v"(q1) : "v"(d0), "v"(d1));
+                const float q = pwb_row16_sum(q0 + q1);
+                if ((l31 & 15) == 0)
+                    reinterpret_cast<float4*>(p.stats)[((size_t)b * p.Cout + co) * slots + 2 * px_t + (l31 >> 4)] = make_float4(32.0f, s1, q, 0.0f);
+            }
+        }
+    }
+}
+
+static bool pwbk_on() { static const bool on = [] { const char* e = std::getenv("SISIC_POINTWISE_KSPLIT"); return !e || std::atoi(e) != 0; }(); return on; }
+template <int PRO>
+static int launch_pwbk(sisic_ctx* ctx, PwbParams& p, int Cin, hipStream_t s) {
+    p.n_co_items = p.Cout / 64;
+    p.n_px = p.HW / 32;
+    const int64_t nitems = (int64_t)p.B * p.n_px * p.n_co_items;
+    SISIC_REQUIRE(nitems > 0 && nitems < (int64_t(1) << 31), "conv2d(pointwise bf16x3, K-split): grid too large");
+    p.nitems = (int)nitems;
+    p.nwg = p.nitems;
+    const size_t lds = sizeof(float) * (size_t)(PWB_WAVES * 32 * 64 + (PRO ? 2 * Cin : 0));
+    static std::atomic<uint64_t> opt{0};
+    auto kern = conv_pwbk_kernel<PRO>;
+    SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)lds, opt));
+    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(64 * PWB_WAVES), lds, s, p);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
+// staged form: LDS holds the image's 64 pixels of every input channel as split operands (6 bytes per value) and the GroupNorm table
+static size_t pwbs_lds_bytes(int Cin) { return (size_t)(Cin / 8) * 2 * 64 * 24 + 8 * (size_t)Cin; }
+static bool pwbs_applicable(const sisic_conv_args& a) {
+    const int items = a.Cout / 64;
+    return items >= 6 && items <= PWBS_MAX_WAVES && pwbs_lds_bytes(a.c0 + a.c1) <= 150 * 1024;
+}
+template <int PRO>
+static int launch_pwbs(sisic_ctx* ctx, PwbParams& p, int Cin, hipStream_t s) {
+    p.n_co_items = p.Cout / 64;
+    p.n_px = p.HW / 64;
+    const int64_t nwg = (int64_t)p.B * p.n_px;
+    SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d(pointwise bf16x3, staged): grid too large");
+    p.nwg = (int)nwg;
+    p.nitems = p.nwg * p.n_co_items;
+    const size_t lds = pwbs_lds_bytes(Cin);
+    static std::atomic<uint64_t> opt{0};
+    auto kern = conv_pwbs_kernel<PRO>;
+    SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)lds, opt));
+    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(64 * p.n_co_items), lds, s, p);
+    SISIC_HIP(hipGetLastError());
+    return SISIC_OK;
+}
+
 // The shapes this kernel takes: whole 64-pixel and 64-channel tiles, whole 8-channel chunks with the concat seam on a chunk
 // boundary, 8-byte aligned pixel pairs, 32-bit byte offsets inside an image of either operand and inside the filter tensor.
 bool conv_pointwise_bf3_applicable(const sisic_conv_args& a) {
@@ -387,6 +807,27 @@ int launch_conv_pointwise_bf3(sisic_ctx* ctx, const sisic_conv_args& a, hipStrea
     // 64-pixel items where they give every SIMD at least two waves (1024 SIMDs), 32-pixel items otherwise: a lone wave has
     // nobody to hide its latencies.  (The choice depends on the batch; the bits of an output do not: its chain of MFMAs is the same.)
     // (tile_cfg 29 / 30 force the 32- / 64-pixel form: tests of their bit-equality)
+    // the K-split form (tile_cfg 35 forces it) for the 16x16 and 8x8 levels' layers of up to 256 output channels -- by SHAPE only:
+    // its bits are its own.  Measured at batch 64 (profiles/r04/conv_bench_pointwise_forms.txt): 256 -> 256 @16 27.3 vs 34.2 us,
+    // 512 -> 256 @8 13.5 vs 24.9, 512 -> 256 @16 38.0 vs 38.7; NOT for 256 -> 768 (76.8 vs 50.7: twelve channel items already
+    // fill the chip, and four waves per item fetch the item's filters in four strands)
+    {
+        const bool ks_ok = p.nchunks % (4 * PWB_WAVES) == 0;        // (whole groups of four chunks per wave; the concat seam lies on a chunk boundary)
+        if (a.tile_cfg == 35) SISIC_REQUIRE(ks_ok, "conv2d(pointwise bf16x3, K-split): tile_cfg 35 needs a multiple of 128 input channels");
+        if (a.tile_cfg == 35 || (a.tile_cfg == 0 && ks_ok && p.HW <= 256 && a.Cout <= 256 && pwbk_on())) {
+            if (pro == 2) return launch_pwbk<2>(ctx, p, Cin, s);
+            if (pro == 1) return launch_pwbk<1>(ctx, p, Cin, s);
+            return launch_pwbk<0>(ctx, p, Cin, s);
+        }
+    }
+    // the staged form (tile_cfg 34 forces it) where a layer has 6 .. 12 channel items and enough 64-pixel workgroups for the chip
+    // (the choice depends on the batch; the bits do not)
+    if (a.tile_cfg == 34) SISIC_REQUIRE(pwbs_applicable(a), "conv2d(pointwise bf16x3, staged): tile_cfg 34 needs 384 .. 768 output channels and at most %d input channels", (150 * 1024) / 392);
+    if (a.tile_cfg == 34 || (a.tile_cfg == 0 && pwbs_applicable(a) && (int64_t)a.B * (p.HW / 64) >= 128)) {
+        if (pro == 2) return launch_pwbs<2>(ctx, p, Cin, s);
+        if (pro == 1) return launch_pwbs<1>(ctx, p, Cin, s);
+        return launch_pwbs<0>(ctx, p, Cin, s);
+    }
     const bool wide = a.tile_cfg == 29 ? false : (a.tile_cfg == 30 ? true : (int64_t)a.B * (p.HW / 64) * (a.Cout / 64) >= 2048);
     if (wide) {
         if (pro == 2) return launch_pwb<2, 2>(ctx, p, Cin, s);

@@ -471,8 +471,10 @@ def test_conv1x1_pointwise(B, c0, c1, cout, H, W):
         _close(y, _conv_ref(x, w, **kw), what="pointwise conv1x1")
         assert torch.equal(y, _run_conv(x, w, 25, **kw))
         # the auto dispatch: the bf16x3 kernel (tile_cfg 28) where its 64-pixel x 64-channel tiles are whole, this one otherwise
+        #   (and its K-split form, tile_cfg 35, for the small levels' layers -- a rule of the layer's shape alone)
         bf3 = cout % 64 == 0 and (H * W) % 64 == 0 and (c0 + c1) % 8 == 0 and c0 % 8 == 0
-        assert torch.equal(_run_conv(x, w, 0, **kw), _run_conv(x, w, 28, **kw) if bf3 else y)
+        ksplit = bf3 and H * W <= 256 and cout <= 256 and (c0 + c1) % 128 == 0
+        assert torch.equal(_run_conv(x, w, 0, **kw), _run_conv(x, w, 35 if ksplit else 28, **kw) if bf3 else y)
     # GroupNorm partials of the result: one slot per 32 pixels
     d = lambda t: None if t is None else t.to(DEV).contiguous()
     y, st = ops.conv2d(d(x), ops.pack_conv_weight(d(w)), cout, 1, bias=d(b), x2=d(x2), residual=d(res), tile_cfg=20, with_stats=True)
@@ -638,6 +640,59 @@ def test_conv1x1_pointwise_bf16x3_item_width_does_not_change_bits():
         ya, sa = ops.conv2d(d(x), wp, cout, 1, bias=d(b), tile_cfg=29, with_stats=True, **kw)
         yb, sb = ops.conv2d(d(x), wp, cout, 1, bias=d(b), tile_cfg=30, with_stats=True, **kw)
         assert torch.equal(ya, yb) and torch.equal(sa, sb)
+        # ... and the staged form (tile_cfg 34: the pixels' operands split once per workgroup into LDS, a wave per channel item)
+        yc, sc = ops.conv2d(d(x), wp, cout, 1, bias=d(b), tile_cfg=34, with_stats=True, **kw)
+        assert torch.equal(ya, yc) and torch.equal(sa, sc)
+
+
+def test_conv1x1_pointwise_bf16x3_staged_qkv_shape():
+    """The attention blocks' q, k, v projection (256 -> 768 at 16x16 behind a GroupNorm): the staged form against float64 and,
+    bit for bit, against the per-wave form it replaces; a concatenated input as well (the seam on a chunk boundary)."""
+    from synt_isic_amd import ops
+    d = lambda t: t.to(DEV).contiguous()
+    for (c0, c1, cout, H, W, B) in ((256, 0, 768, 16, 16, 3), (128, 64, 384, 8, 16, 2)):
+        cin = c0 + c1
+        x, x2 = _rand(B, c0, H, W, seed=460), (_rand(B, c1, H, W, seed=461) if c1 else None)
+        w = _rand(cout, cin, 1, 1, seed=462, scale=cin ** -0.5)
+        b = _rand(cout, seed=463)
+        gn = (1.0 + 0.3 * _rand(B, cin, seed=464), 0.3 * _rand(B, cin, seed=465))
+        xx = x if x2 is None else torch.cat([x, x2], 1)
+        ref = _conv_ref(xx, w, bias=b, gn=gn, gn_silu=False)
+        wp = ops.pack_conv_weight(d(w))
+        kw = dict(bias=d(b), x2=None if x2 is None else d(x2), gn_scale=d(gn[0]), gn_shift=d(gn[1]), gn_silu=False, with_stats=True)
+        ys, ss = ops.conv2d(d(x), wp, cout, 1, tile_cfg=34, **kw)
+        yw, sw = ops.conv2d(d(x), wp, cout, 1, tile_cfg=30, **kw)
+        _close(ys, ref, what=f"staged bf16x3 pointwise {cin}->{cout}")
+        assert torch.equal(ys, yw) and torch.equal(ss, sw)
+
+
+def test_conv1x1_pointwise_bf16x3_ksplit():
+    """tile_cfg 35 (the small levels' 1x1 layers: a workgroup's four waves split the input channels): against float64 with every
+    fused feature; the GroupNorm partials against the stored tensor's statistics; and an image's bits do not depend on its batch
+    (the form is chosen by layer shape, its summation order is fixed)."""
+    from synt_isic_amd import ops
+    d = lambda t: t.to(DEV).contiguous()
+    for (c0, c1, cout, H, W, B) in ((256, 0, 256, 16, 16, 3), (256, 256, 256, 8, 8, 4), (128, 0, 192, 8, 16, 2)):
+        cin = c0 + c1
+        x, x2 = _rand(B, c0, H, W, seed=470), (_rand(B, c1, H, W, seed=471) if c1 else None)
+        xx = x if x2 is None else torch.cat([x, x2], 1)
+        w = _rand(cout, cin, 1, 1, seed=472, scale=cin ** -0.5)
+        b, res, cb = _rand(cout, seed=473), _rand(B, cout, H, W, seed=474), _rand(B, cout, seed=475)
+        gn = (1.0 + 0.3 * _rand(B, cin, seed=476), 0.3 * _rand(B, cin, seed=477))
+        wp = ops.pack_conv_weight(d(w))
+        x2d = None if x2 is None else d(x2)
+        for kw, rkw in ((dict(), dict()),
+                        (dict(residual=d(res), relu=True), dict(residual=res, relu=True)),
+                        (dict(chan_bias=d(cb), gn_scale=d(gn[0]), gn_shift=d(gn[1]), gn_silu=True), dict(chan_bias=cb, gn=gn, gn_silu=True))):
+            y, st = ops.conv2d(d(x), wp, cout, 1, bias=d(b), x2=x2d, tile_cfg=35, with_stats=True, **kw)
+            _close(y, _conv_ref(xx, w, bias=b, **rkw), what=f"K-split bf16x3 pointwise {cin}->{cout}@{H}x{W} {sorted(kw)}")
+            y1, st1 = ops.conv2d(d(x[1:2]), wp, cout, 1, bias=d(b), x2=None if x2 is None else d(x2[1:2]), tile_cfg=35, with_stats=True,
+                                 **{k: (v[1:2].contiguous() if torch.is_tensor(v) else v) for k, v in kw.items()})
+            assert torch.equal(y[1:2], y1) and torch.equal(st[1:2], st1)
+            # partials: slot = 32 consecutive pixels: (32, sum, centred sum of squares)
+            yv = y.double().cpu().reshape(B, cout, -1, 32)
+            assert torch.allclose(st[..., 1].double().cpu(), yv.sum(-1), rtol=1e-5, atol=1e-4)
+            assert torch.allclose(st[..., 2].double().cpu(), ((yv - yv.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
 
 
 def test_conv_reference_layer_shapes():
