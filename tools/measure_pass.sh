@@ -13,11 +13,11 @@ echo "pytest rc=$rc"; tail -4 gpurun_out/pytest_gpu.log
 if [ $rc -ne 0 ] || grep -q "Memory access fault" gpurun_out/pytest_gpu.log; then tail -40 gpurun_out/pytest_gpu.log; exit 1; fi
 timeout -k 10 600 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.log || { tail -5 gpurun_out/bench_default.log; exit 1; }
 tail -4 gpurun_out/bench_default.log
-bash tools/prof_stats.sh r03 | cut -c1-150 | head -14
+bash tools/prof_stats.sh r04 | cut -c1-150 | head -14
 cd $R && bash tools/prof_pmc.sh sq SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE | cut -c1-200 | head -8
 cd $R && bash tools/prof_pmc.sh fetch FETCH_SIZE GRBM_GUI_ACTIVE | cut -c1-200 | head -6
 cd $R && bash tools/prof_pmc.sh write WRITE_SIZE | cut -c1-200 | head -6
-cd $R && python tools/make_pmc_summary.py gpurun_out gpurun_out/pmc_summary_r03.json
+cd $R && python tools/make_pmc_summary.py gpurun_out gpurun_out/pmc_summary_r04.json
 # per-layer: the bf16x3 kernels against the f32 forms they replace (B = 64), the per-wave timeline of the bf16x3 Winograd kernel,
 # the training step and batch-1 latency with the round's final library
 cd $R
