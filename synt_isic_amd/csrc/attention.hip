@@ -52,23 +52,14 @@ constexpr int ATT_WAVES = 4;
 // QB: 32-query blocks per wave.  With two, a key's K operands and its eight V values -- two broadcast ds_read_b128, the LDS
 // traffic this loop is bound by -- are read once for 64 queries, and a workgroup stages the head's K / V once for 256 queries.
 // A query's arithmetic does not depend on QB (same keys, same order, same operations): the choice may follow the batch.
-// PVM: P.V on the matrix pipe as well (round 4).  O^T = V^T P^T per 32-key tile: A = the tile's V, pre-split into three bf16 terms
-// and laid out as 32 ROWS = (term, d) -- rows 0-7 V_hi, 8-15 V_mid, 16-23 V_lo, 24-31 zero -- so that ONE MFMA multiplies all
-// three terms of V by one term of P; B = a term of the lane's own probabilities (its 16 score registers ARE the B layout: keys
-// on the lane's registers, the query on the lane); three MFMAs (p_hi, p_mid, p_lo) per 16 keys give all nine term products, and
-// the lane sums its rows r, r + 4, r + 8 into O[d = 4 half + r].  P is split exactly like every other operand here, so the sum is
-// fp32-equivalent; the price is the split (88 plain vector instructions per tile and query block against 64 packed FMAs) and
-// six MFMAs, the gain 26 fewer LDS reads per tile.
-template <int QB, bool PVM>
+template <int QB>
 __global__ void __launch_bounds__(64 * ATT_WAVES)
 attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, int N, int heads, int q_blocks,
                  float scale) {
     // K of the block, split: per dimension group g (d = 4 g .. 4 g + 3) and key the packed terms (hi, mid) [4 dwords] and lo [2]
     __shared__ __attribute__((aligned(16))) unsigned Kh[2 * ATT_KB * 4];
     __shared__ __attribute__((aligned(16))) unsigned Kl[2 * ATT_KB * 2];
-    __shared__ __attribute__((aligned(16))) float Vs[PVM ? 4 : ATT_D * ATT_KB];
-    // PVM: [32-key tile][MFMA 0 / 1][half][row = (term, d)][8 keys] bf16: a lane's A operand is one 16-byte read
-    __shared__ __attribute__((aligned(16))) unsigned short Va[PVM ? ATT_KT * 2 * 2 * 32 * 8 : 8];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_D * ATT_KB];
 
     int blk = blockIdx.x;
     const int qb = blk % q_blocks;
@@ -105,20 +96,11 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
 
     float m_run[QB], l_part[QB];
     f32x2 o2[QB][ATT_D / 2];
-    float o4[QB][4];                 // PVM: O[d = 4 half + r] of the lane's query
 #pragma unroll
     for (int j = 0; j < QB; ++j) {
         m_run[j] = -INFINITY; l_part[j] = 0.0f;
 #pragma unroll
         for (int d = 0; d < ATT_D / 2; ++d) o2[j][d] = f32x2{0.0f, 0.0f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o4[j][r] = 0.0f;
-    }
-    if constexpr (PVM) {             // rows 24 .. 31 of every A operand stay zero
-        for (int i = threadIdx.x; i < ATT_KT * 2 * 2 * 8 * 8 / 2; i += 64 * ATT_WAVES) {
-            const int blk = i / 32, w = i % 32;          // 8 rows x 8 keys x 2 bytes = 32 dwords per (tile, MFMA, half)
-            reinterpret_cast<unsigned*>(Va)[blk * 128 + 96 + w] = 0u;
-        }
     }
 
     // One pass per 32-key tile with an online softmax (running maximum m_run, running sum l_part, running
@@ -166,49 +148,11 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
             // (s_nop: alpha comes from v_exp_f32, and the hazard recognizer does not look inside an asm -- a vector instruction
             //  that reads a transcendental's result in the next slot reads the old register; found as garbage in the masked tile)
             asm("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(l_part[j]) : "v"(l_part[j]), "v"(alpha));
-            if constexpr (PVM) {
+            const f32x2 a2 = f32x2{alpha, alpha};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) asm("s_nop 1\n\tv_mul_f32 %0, %1, %2" : "=v"(o4[j][r]) : "v"(o4[j][r]), "v"(alpha));
-            } else {
-                const f32x2 a2 = f32x2{alpha, alpha};
-#pragma unroll
-                for (int d = 0; d < ATT_D / 2; ++d) asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(o2[j][d]) : "v"(o2[j][d]), "v"(a2));
-            }
+            for (int d = 0; d < ATT_D / 2; ++d) asm("s_nop 1\n\tv_pk_mul_f32 %0, %1, %2" : "=v"(o2[j][d]) : "v"(o2[j][d]), "v"(a2));
             m_run[j] = m_new[j];
         }
-        if constexpr (PVM) {
-            f32x16 O[QB];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {                // the tile's two halves of 16 keys: score registers 8 i .. 8 i + 7
-                const att_u4 a_v = *reinterpret_cast<const att_u4*>(&Va[(((kt * 2 + i) * 2 + half) * 32 + l31) * 8]);
-#pragma unroll
-                for (int j = 0; j < QB; ++j) {
-                    const f32x2 mm = f32x2{m_new[j], m_new[j]};
-                    float pe[8];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const f32x2 dd = f32x2{S[j][8 * i + 2 * k], S[j][8 * i + 2 * k + 1]} - mm;
-                        pe[2 * k] = __builtin_amdgcn_exp2f(dd.x); pe[2 * k + 1] = __builtin_amdgcn_exp2f(dd.y);      // masked keys: 2^(-inf) = 0
-                    }
-                    l_part[j] += ((pe[0] + pe[1]) + (pe[2] + pe[3])) + ((pe[4] + pe[5]) + (pe[6] + pe[7]));
-                    unsigned ph[4], pm[4], pl[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) att_split2(pe[2 * k], pe[2 * k + 1], ph[k], pm[k], pl[k]);
-                    if (i == 0) {
-                        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-                        O[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_v), __builtin_bit_cast(att_bf16x8, att_u4{ph[0], ph[1], ph[2], ph[3]}), zero, 0, 0, 0);
-                    } else {
-                        O[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_v), __builtin_bit_cast(att_bf16x8, att_u4{ph[0], ph[1], ph[2], ph[3]}), O[j], 0, 0, 0);
-                    }
-                    O[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_v), __builtin_bit_cast(att_bf16x8, att_u4{pm[0], pm[1], pm[2], pm[3]}), O[j], 0, 0, 0);
-                    O[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(att_bf16x8, a_v), __builtin_bit_cast(att_bf16x8, att_u4{pl[0], pl[1], pl[2], pl[3]}), O[j], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < QB; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o4[j][r] += (O[j][r] + O[j][r + 4]) + O[j][r + 8];      // rows (hi, mid, lo) x d = 4 half + r
-        } else {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             float pv[QB][4];
@@ -236,7 +180,6 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
                 }
             }
         }
-        }
     };
 
     for (int kb0 = 0; kb0 < N; kb0 += ATT_KB) {
@@ -258,25 +201,8 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
             float v[ATT_D];
 #pragma unroll
             for (int d = 0; d < ATT_D; ++d) v[d] = key < N ? Vp[(size_t)d * N + key] : 0.0f;
-            if constexpr (PVM) {
-                // key k of the block -> (tile, MFMA i, half h, slot e) in the order the score registers hold the keys:
-                // key = 16 i + (e & 3) + 8 (e >> 2) + 4 h inside its tile
-                const int t = k >> 5, i = (k >> 4) & 1, k4 = k & 15, h = (k4 >> 2) & 1, e = (k4 & 3) + 4 * (k4 >> 3);
-                unsigned short* dst = &Va[(((t * 2 + i) * 2 + h) * 32) * 8 + e];
-#pragma unroll
-                for (int d = 0; d < ATT_D; ++d) {
-                    const unsigned hi = __float_as_uint(v[d]) & 0xffff0000u;
-                    const float r1 = v[d] - __uint_as_float(hi);
-                    const unsigned mid = __float_as_uint(r1) & 0xffff0000u;
-                    const float r2 = r1 - __uint_as_float(mid);
-                    dst[(0 * 8 + d) * 8] = (unsigned short)(hi >> 16);
-                    dst[(1 * 8 + d) * 8] = (unsigned short)(mid >> 16);
-                    dst[(2 * 8 + d) * 8] = (unsigned short)(__float_as_uint(r2) >> 16);
-                }
-            } else {
-                *reinterpret_cast<float4*>(&Vs[k * ATT_D]) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(&Vs[k * ATT_D + 4]) = make_float4(v[4], v[5], v[6], v[7]);
-            }
+            *reinterpret_cast<float4*>(&Vs[k * ATT_D]) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(&Vs[k * ATT_D + 4]) = make_float4(v[4], v[5], v[6], v[7]);
         }
         __syncthreads();
         if (!wave_active) continue;
@@ -292,31 +218,22 @@ attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int C, 
 #pragma unroll
         for (int j = 0; j < QB; ++j) {
             const int q = q0 + 32 * j + l31;
+            float o[ATT_D];
+#pragma unroll
+            for (int d = 0; d < ATT_D / 2; ++d) { o[2 * d] = o2[j][d].x; o[2 * d + 1] = o2[j][d].y; }
             const float l_tot = l_part[j] + __shfl_xor(l_part[j], 32, 64);
             const float inv = 1.0f / l_tot;
-            if constexpr (PVM) {
-                // the lane holds O[d = 4 half + r] of its query already
-                if (q < N) {
-                    float* Op = out + ((size_t)b * C + (size_t)head * ATT_D) * N + q;
+            float res[ATT_D];
 #pragma unroll
-                    for (int dd = 0; dd < 4; ++dd) Op[(size_t)(4 * half + dd) * N] = o4[j][dd] * inv;
-                }
-            } else {
-                float o[ATT_D];
+            for (int d = 0; d < ATT_D; ++d) res[d] = (o[d] + __shfl_xor(o[d], 32, 64)) * inv;
+            if (q < N) {
+                float* Op = out + ((size_t)b * C + (size_t)head * ATT_D) * N + q;
 #pragma unroll
-                for (int d = 0; d < ATT_D / 2; ++d) { o[2 * d] = o2[j][d].x; o[2 * d + 1] = o2[j][d].y; }
-                float res[ATT_D];
-#pragma unroll
-                for (int d = 0; d < ATT_D; ++d) res[d] = (o[d] + __shfl_xor(o[d], 32, 64)) * inv;
-                if (q < N) {
-                    float* Op = out + ((size_t)b * C + (size_t)head * ATT_D) * N + q;
-#pragma unroll
-                    for (int dd = 0; dd < 4; ++dd) {
-                        // bitwise select: a plain ?: on the array makes hipcc index it through scratch memory
-                        const int hm = -half;
-                        const float v = __int_as_float((__float_as_int(res[dd]) & ~hm) | (__float_as_int(res[4 + dd]) & hm));
-                        Op[(size_t)(4 * half + dd) * N] = v;
-                    }
+                for (int dd = 0; dd < 4; ++dd) {
+                    // bitwise select: a plain ?: on the array makes hipcc index it through scratch memory
+                    const int hm = -half;
+                    const float v = __int_as_float((__float_as_int(res[dd]) & ~hm) | (__float_as_int(res[4 + dd]) & hm));
+                    Op[(size_t)(4 * half + dd) * N] = v;
                 }
             }
         }
@@ -337,15 +254,10 @@ int launch_attention(sisic_ctx* ctx, const float* qkv, float* out, int B, int C,
     SISIC_REQUIRE(grid < (int64_t(1) << 31), "attention: grid too large");
     ProfileScope prof(ctx, s, PK_ATTN, 16.0 * B * C * N, 4.0 * B * C * double(N) * N);
     const float scale = 1.4426950408889634f / sqrtf((float)head_dim);     // head_dim^-1/2 * log2(e)
-    // SISIC_ATT_PV_MFMA=0: round 3's P.V on the vector ALU (A/B builds; another summation order, other bits)
-    static const bool pvm = [] { const char* e = std::getenv("SISIC_ATT_PV_MFMA"); return !e || std::atoi(e) != 0; }();
-    if (pvm) {
-        if (qb == 2) hipLaunchKernelGGL((attention_kernel<2, true>), dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
-        else hipLaunchKernelGGL((attention_kernel<1, true>), dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
-    } else {
-        if (qb == 2) hipLaunchKernelGGL((attention_kernel<2, false>), dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
-        else hipLaunchKernelGGL((attention_kernel<1, false>), dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
-    }
+    if (qb == 2)
+        hipLaunchKernelGGL(attention_kernel<2>, dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
+    else
+        hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)grid), dim3(64 * ATT_WAVES), 0, s, qkv, out, C, N, heads, q_blocks, scale);
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }
