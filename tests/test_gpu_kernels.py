@@ -1068,6 +1068,7 @@ def test_conv2d_auto_dispatch_fuzz():
 
 @pytest.mark.parametrize("cfg,k,ups,B,H,W,cin,cout", [
     (20, 1, False, 2, 16, 16, 64, 64), (22, 1, False, 2, 12, 20, 40, 70), (28, 1, False, 2, 16, 16, 136, 128),
+    (34, 1, False, 2, 16, 16, 64, 384), (35, 1, False, 2, 16, 16, 256, 128),   # the staged and the K-split 1x1 forms
     (0, 3, True, 2, 10, 14, 24, 40),            # the generic MFMA path with a nearest-2x input
     (74, 3, False, 3, 32, 32, 72, 64), (92, 3, False, 5, 8, 8, 128, 64), (0, 3, False, 2, 8, 8, 64, 64), (60, 3, False, 2, 18, 10, 24, 70),
     (4, 3, False, 2, 9, 5, 16, 64), (50, 3, False, 2, 16, 16, 20, 3), (11, 3, False, 2, 16, 16, 16, 64)])
