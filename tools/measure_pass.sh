@@ -29,8 +29,8 @@ cd $R
   timeout -k 10 300 python tools/conv_bench.py --cfgs 91,92 --match "@8 gn" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
   echo "# python tools/conv_bench.py --cfgs 66,74 --match 'up ': the nearest-2x upsample convolutions, nine-position f32 form vs the bf16x3 form (16 positions)"
   timeout -k 10 300 python tools/conv_bench.py --cfgs 66,74 --match "up " --iters 30 2>&1 | grep -v "amdgpu\|best cfg"
-  echo "# python tools/conv_bench.py --cfgs 20,28 --match 1x1: the 1x1 layers, f32 pointwise kernel vs the bf16x3 pointwise kernel"
-  timeout -k 10 300 python tools/conv_bench.py --cfgs 20,28 --match "1x1" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"; } > gpurun_out/conv_bench_bf16x3.txt || exit 1
+  echo "# python tools/conv_bench.py --cfgs 20,28,34,35 --match 1x1: the 1x1 layers, f32 pointwise kernel vs the bf16x3 forms (28 per wave, 34 staged, 35 K-split)"
+  timeout -k 10 300 python tools/conv_bench.py --cfgs 20,28,34,35 --match "1x1" --iters 30 2>&1 | grep -v "amdgpu\|best cfg"; } > gpurun_out/conv_bench_bf16x3.txt || exit 1
 tail -3 gpurun_out/conv_bench_bf16x3.txt
 if [ -f tools/bin/libsisic_hip_timing.so ]; then
     { SISIC_LIB_PATH=$R/tools/bin/libsisic_hip_timing.so timeout -k 10 200 python tools/bf3_timeline.py --cin 64 2>&1 | grep -v amdgpu

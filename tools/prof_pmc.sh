@@ -8,7 +8,7 @@ mkdir -p "$root/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$tag
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$tag -o $tag -- \
-    python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --profile-steps 0 > "$root/gpurun_out/${tag}_pmc.log" 2>&1
+    python3 "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-validate --profile-steps 0 > "$root/gpurun_out/${tag}_pmc.log" 2>&1
 f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
 test -n "$f"
 python3 - "$f" "$root/gpurun_out/${tag}_counters.csv" <<'PY'
