@@ -56,9 +56,11 @@ def test_unet_forward_128_golden(golden_dir, synthetic_sd):
 
 
 def test_sample_T1000_golden_prefix(golden_dir, synthetic_sd):
-    """The 1000-step fixture, replayed for its first 100 steps on the CPU path (the whole chain is replayed by the GPU
-    test; here it would take the larger part of a minute)."""
+    """The 1000-step fixture on the CPU path: its first step always; its first 100 steps (to the fixture's second kept frame)
+    with SISIC_SLOW_TESTS=1 -- five minutes on eight shared cores, and the whole chain is replayed by the GPU test
+    (tests/test_gpu_sampler.py) against the same file."""
     from oracle import ddpm
+    n_replay = 100 if os.environ.get("SISIC_SLOW_TESTS") == "1" else 1
     g = np.load(os.path.join(golden_dir, "sample_T1000_seed3_32.npz"))
     assert [int(s) for s in g["steps"]] == [0, 99, 499, 899, 999]
     sched = ddpm.DDPMSchedulerOracle()
@@ -66,10 +68,11 @@ def test_sample_T1000_golden_prefix(golden_dir, synthetic_sd):
     gen = torch.Generator().manual_seed(3)
     x = torch.randn(1, 3, 32, 32, generator=gen)
     with torch.no_grad():
-        for i, t in enumerate(sched.timesteps[:100]):
+        for i, t in enumerate(sched.timesteps[:n_replay]):
             eps = unet.unet_forward(synthetic_sd, x, int(t))
             z = torch.randn(1, 3, 32, 32, generator=gen)
             x = sched.step(eps, int(t), x, noise=z)
             if i == 0:
                 np.testing.assert_allclose(x.numpy(), g["traj"][0], rtol=0, atol=1e-5)
-    np.testing.assert_allclose(x.numpy(), g["traj"][1], rtol=0, atol=5e-4)
+    if n_replay == 100:
+        np.testing.assert_allclose(x.numpy(), g["traj"][1], rtol=0, atol=5e-4)
