@@ -556,6 +556,12 @@ def main():
     if rank == 0:
         line = bench_line(value=value, world=world, K=K, W=W, ms_per_step=ms_per_step, B=B, roofline=roofline, cpu=cpu, e2e=e2e,
                           validated=validated)
+        if sdist.share_gpu_rehearsal():
+            # SISIC_SHARE_GPU=1 (synt_isic_amd/dist.py): the ranks shared this box's GPU(s) -- a rehearsal of the N-rank control
+            # flow, not a measurement
+            line["shared_gpu_rehearsal"] = True
+            line["backend"] = torch.distributed.get_backend() if world > 1 else None
+            line["value_is_valid"] = False
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

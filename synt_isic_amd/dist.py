@@ -35,6 +35,13 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if share_gpu_rehearsal() and torch.cuda.is_available():
+        # SISIC_SHARE_GPU=1: a REHEARSAL of the N-rank path on a box with fewer GPUs than ranks (the builder's boxes have one):
+        # ranks take device LOCAL_RANK % device_count and the collectives go through gloo on host copies (RCCL refuses two
+        # ranks on one device).  Launcher, rendezvous, sharding, gather and the max-over-ranks are the real ones; the
+        # throughput of such a run means nothing.
+        local = local % torch.cuda.device_count()
+        backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -44,6 +51,15 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def share_gpu_rehearsal() -> bool:
+    return os.environ.get("SISIC_SHARE_GPU", "0") == "1"
+
+
+def _host_collectives() -> bool:
+    """gloo moves host memory: device tensors are staged through the host for its collectives (the rehearsal mode)"""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
 
 
 def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
@@ -67,6 +83,9 @@ def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[t
         pad = torch.zeros((b_max - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send = torch.cat([local, pad], dim=0)
     send = send.contiguous()
+    dev = send.device
+    if _host_collectives() and dev.type != "cpu":
+        send = send.cpu()
     bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, gather_list=bufs, dst=dst)
     if rank != dst:
@@ -75,12 +94,12 @@ def gather_images(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[t
     for r in range(world):
         rlo, rhi = shard_range(n_total, world, r)
         parts.append(bufs[r][: rhi - rlo])
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).to(dev)
 
 
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if _host_collectives() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -153,6 +153,41 @@ def test_nccl_world1_gather_and_max():
         dist.destroy_process_group()
 
 
+def test_two_ranks_share_the_gpu_rehearsal(tmp_path):
+    """the N > 1 path beyond one rank, on the one GPU a test box has.  SISIC_SHARE_GPU=1
+    (synt_isic_amd/dist.py) lets two ranks take the same device with gloo collectives on host copies: launcher, rendezvous on
+    127.0.0.1, contiguous seed shards, two concurrent samplers, the gather and the max-over-ranks are the real code.
+    (a) examples/generate_sharded.py with two ranks: the gathered images are bit-identical to the same seeds on one rank;
+    (b) `python bench.py --gpus 2` starts its own two ranks, both pass the post-clock validation, one JSON line, n_gpus 2."""
+    import json
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SISIC_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for world in (1, 2):
+        out = str(tmp_path / f"images_{world}.npy")
+        if world == 1:
+            cmd = [sys.executable, os.path.join(root, "examples", "generate_sharded.py")]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", "29531", os.path.join(root, "examples", "generate_sharded.py")]
+        r = subprocess.run(cmd + ["--count", "6", "--T", "3", "--size", "64", "--batch", "4", "--out", out], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[world] = np.load(out)
+    assert outs[1].shape == (6, 64, 64, 3) and np.array_equal(outs[1], outs[2])
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                        "--no-cpu-baseline", "--no-e2e", "--profile-steps", "1"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["shared_gpu_rehearsal"] is True and d["backend"] == "gloo"
+    assert d["validated"]["image0_bit_equal_to_its_B1_run"] and d["validated"]["all_latents_finite"]
+
+
 BF3_LAUNCHES_PER_STEP = 33.0      # the stride-1 conv3x3 launches of a step with 64-channel x 16x16-pixel tiles (12 + 9 + 9) + 3 upsample
 
 
