@@ -600,7 +600,7 @@ static int dispatch_conv2d(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t
                       (use_wino && winograd_cfg(a) == 74) ? PK_WINO_BF3 :
                       (use_wino && !wino_ups9 && (winograd_cfg(a) == 66 || (winograd_cfg(a) >= 68 && winograd_cfg(a) <= 73) || winograd_cfg(a) == 78 || winograd_cfg(a) == 79)) ? PK_WINO_MAIN : -1);
 
-    if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || cfg == 50 || cfg == 51)) {
+    if (a.ksize == 3 && a.stride == 1 && !a.upsample && a.Cout <= 4 && (cfg == 0 || (cfg >= 50 && cfg <= 52))) {
         if (slots_query) return SISIC_OK;             // no partials from this kernel (slots stay 0)
         return launch_conv_smallcout(ctx, a, s);      // conv_out: vector-ALU kernel, conv_small.hip
     }

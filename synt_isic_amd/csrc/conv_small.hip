@@ -11,6 +11,9 @@
 // Same packed weight layout as conv_mfma.hip ([Cin_pad][9][Cout_pad]): the first 4 floats of each row.
 //
 // Algorithmic bytes: 4*B*(Cin + Cout)*H*W (+ weights); HBM-bound.
+#include <atomic>
+#include <type_traits>
+
 #include "common.h"
 
 namespace sisic {
@@ -22,6 +25,10 @@ constexpr int CS_TW = 32, CS_PX = 4, CS_CIC = 2;
 constexpr int CS_IW = CS_TW + 2;
 constexpr int CS_IWP = 36;                                       // LDS row stride: float4-aligned rows
 template <int CS_TH>
+struct CSGeom;
+template <int CS_TH, int KS>
+constexpr size_t cs_lds_bytes();
+template <int CS_TH>
 struct CSGeom {
     static constexpr int THR = (CS_TW / CS_PX) * CS_TH;          // 256 / 64 threads
     static constexpr int IH = CS_TH + 2;
@@ -31,6 +38,12 @@ struct CSGeom {
     static_assert(CS_IWP >= CS_IW + 2 && CS_IWP % 4 == 0 && CHS % 4 == 0, "aligned rows");
     static_assert(CS_CIC * 9 <= THR, "one thread per filter row");
 };
+
+template <int CS_TH, int KS>
+constexpr size_t cs_lds_bytes() {
+    constexpr size_t in = (size_t)KS * 2 * CS_CIC * CSGeom<CS_TH>::CHS, red = (size_t)(KS - 1) * CS_PX * 4 * CSGeom<CS_TH>::THR;
+    return sizeof(float) * (in > red ? in : red);
+}
 
 struct ConvSmallParams {
     const float* in0;
@@ -51,12 +64,21 @@ struct ConvSmallParams {
     int tiles_x, tiles_y, nchunks;
 };
 
-template <int CS_TH>
-__global__ void __launch_bounds__(CSGeom<CS_TH>::THR, 3) conv3x3_smallcout_kernel(const ConvSmallParams p) {
+// KS (round 4): the input channels split over KS thread groups of one workgroup (each walks 1 / KS of the chunks of the SAME
+// pixel tile, its own LDS buffers), their partial sums added through LDS in the fixed order ((g0 + g1) + g2) + g3.  At batch 64
+// the 32-row tiling is 256 workgroups of four waves -- ONE wave per SIMD, 32 chunks of [load, stage, barrier, multiply] each:
+// latency-bound at 48 us for 67 MB of input; with four groups the chip has four waves per SIMD.  Another summation order, so
+// the choice is by the layer's shape alone (launcher), never by the batch.
+template <int CS_TH, int KS>
+__global__ void __launch_bounds__(CSGeom<CS_TH>::THR * KS, KS == 1 ? 3 : 4) conv3x3_smallcout_kernel(const ConvSmallParams p) {
     constexpr int CS_THR = CSGeom<CS_TH>::THR, CS_IH = CSGeom<CS_TH>::IH, CS_TPC = CSGeom<CS_TH>::TPC, CS_EPT = CSGeom<CS_TH>::EPT,
                   CS_CHS = CSGeom<CS_TH>::CHS;
-    __shared__ __attribute__((aligned(16))) float in_lds[2][CS_CIC * CS_CHS];
-    __shared__ __attribute__((aligned(16))) float w_lds[2][CS_CIC * 9 * 4];
+    constexpr int IN_FLOATS = 2 * CS_CIC * CS_CHS, RED_FLOATS = (KS - 1) * CS_PX * 4 * CS_THR;
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];      // max(KS * IN_FLOATS, RED_FLOATS) floats (launcher)
+    __shared__ __attribute__((aligned(16))) float w_all[KS][2][CS_CIC * 9 * 4];
+    const int grp = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / CS_THR);     // (CS_THR is a multiple of 64)
+    float (*in_lds)[CS_CIC * CS_CHS] = reinterpret_cast<float (*)[CS_CIC * CS_CHS]>(lds_all + grp * IN_FLOATS);
+    float (*w_lds)[CS_CIC * 9 * 4] = w_all[grp];
 
     int tile = blockIdx.x;
     const int tx = tile % p.tiles_x;
@@ -64,10 +86,11 @@ __global__ void __launch_bounds__(CSGeom<CS_TH>::THR, 3) conv3x3_smallcout_kerne
     const int ty = tile % p.tiles_y;
     const int b = tile / p.tiles_y;
     const int oy0 = ty * CS_TH, ox0 = tx * CS_TW;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x - grp * CS_THR;              // the thread's place in its group
     const int sci = tid / CS_TPC, sl = tid % CS_TPC;
     const int HW = p.H * p.W, Cin = p.c0 + p.c1;
     const int prologue = (p.gn_scale == nullptr) ? 0 : (p.gn_silu ? 2 : 1);
+    const int n_mine = p.nchunks / KS, c_first = grp * n_mine;       // this group's chunks (launcher: nchunks % KS == 0)
 
     int goff[CS_EPT];
     unsigned vmask = 0;
@@ -121,12 +144,13 @@ __global__ void __launch_bounds__(CSGeom<CS_TH>::THR, 3) conv3x3_smallcout_kerne
     for (int q = 0; q < CS_PX; ++q)
 #pragma unroll
         for (int co = 0; co < 4; ++co) acc[q][co] = 0.0f;
-    load_chunk(0);
+    load_chunk(c_first);
     store_chunk(0);
     __syncthreads();
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const int buf = chunk & 1;
-        const bool more = chunk + 1 < p.nchunks;
+    for (int k = 0; k < n_mine; ++k) {
+        const int chunk = c_first + k;
+        const int buf = k & 1;
+        const bool more = k + 1 < n_mine;
         if (more) load_chunk(chunk + 1);
         const float* I = &in_lds[buf][py * CS_IWP + px0];
         const float* Wt = &w_lds[buf][0];
@@ -151,6 +175,23 @@ __global__ void __launch_bounds__(CSGeom<CS_TH>::THR, 3) conv3x3_smallcout_kerne
         }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
+    }
+    if constexpr (KS > 1) {
+        // partial sums of groups 1 .. KS-1 through LDS (over the staging buffers: the loop's last barrier is behind every read)
+        if (grp > 0) {
+#pragma unroll
+            for (int q = 0; q < CS_PX; ++q)
+#pragma unroll
+                for (int co = 0; co < 4; ++co) lds_all[((grp - 1) * CS_PX * 4 + q * 4 + co) * CS_THR + tid] = acc[q][co];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+            for (int q = 0; q < CS_PX; ++q)
+#pragma unroll
+                for (int co = 0; co < 4; ++co) acc[q][co] += lds_all[((g - 1) * CS_PX * 4 + q * 4 + co) * CS_THR + tid];
     }
 
     const int oy = oy0 + py, ox = ox0 + px0;
@@ -197,8 +238,27 @@ int launch_conv_smallcout(sisic_ctx* ctx, const sisic_conv_args& a, hipStream_t 
     p.tiles_y = cdiv(a.Hin, spare ? 32 : 8);
     const int64_t nwg = (int64_t)a.B * p.tiles_x * p.tiles_y;
     SISIC_REQUIRE(nwg > 0 && nwg < (int64_t(1) << 31), "conv2d(small): grid too large");
-    if (spare) hipLaunchKernelGGL(conv3x3_smallcout_kernel<32>, dim3((unsigned)nwg), dim3(CSGeom<32>::THR), 0, s, p);
-    else hipLaunchKernelGGL(conv3x3_smallcout_kernel<8>, dim3((unsigned)nwg), dim3(CSGeom<8>::THR), 0, s, p);
+    // four channel groups per workgroup from 32 input channels up (a rule of the layer's shape: the groups' sums are added in
+    // their own order); tile_cfg 52 forces one group
+    const bool ksplit = a.tile_cfg != 52 && p.nchunks % 4 == 0 && p.nchunks >= 16;
+    auto go = [&](auto th_tag, auto ks_tag) -> int {
+        constexpr int TH = decltype(th_tag)::value, KSV = decltype(ks_tag)::value;
+        auto kern = conv3x3_smallcout_kernel<TH, KSV>;
+        static std::atomic<uint64_t> opt{0};
+        SISIC_TRY(ensure_dynamic_lds(ctx, reinterpret_cast<const void*>(kern), (int)(cs_lds_bytes<TH, KSV>()), opt));
+        constexpr size_t lds = cs_lds_bytes<TH, KSV>();
+        constexpr unsigned thr = (unsigned)(CSGeom<TH>::THR * KSV);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(thr), lds, s, p);
+        return SISIC_OK;
+    };
+    using I = std::integral_constant<int, 1>;
+    if (ksplit) {
+        if (spare) SISIC_TRY(go(std::integral_constant<int, 32>{}, std::integral_constant<int, 4>{}));
+        else SISIC_TRY(go(std::integral_constant<int, 8>{}, std::integral_constant<int, 4>{}));
+    } else {
+        if (spare) SISIC_TRY(go(std::integral_constant<int, 32>{}, I{}));
+        else SISIC_TRY(go(std::integral_constant<int, 8>{}, I{}));
+    }
     SISIC_HIP(hipGetLastError());
     return SISIC_OK;
 }

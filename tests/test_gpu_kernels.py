@@ -116,6 +116,11 @@ def test_conv3x3_small_cout_kernel(H, W):
             _close(_run_conv(x, w, cfg, **kw), _conv_ref(x, w, **kw), what=f"small-cout fused {cout} cfg{cfg}")
         # the 32-row and the 8-row tile (picked from the number of workgroups) sum a pixel's channels in the same order
         assert torch.equal(outs[50], outs[51]) and torch.equal(outs[0], outs[50])
+        # (from 32 input channels up every tiling splits the channels over four thread groups -- a rule of the shape; tile_cfg 52
+        #  is the one-group form, another summation order)
+        kw = dict(bias=b, x2=x2, gn=gn, gn_silu=True)
+        _close(_run_conv(x, w, 52, **kw), _conv_ref(x, w, **kw), what=f"small-cout {cout} one channel group {H}x{W}")
+        assert torch.equal(_run_conv(x[1:2], w, 0, bias=b, x2=x2[1:2], gn=(gn[0][1:2], gn[1][1:2]), gn_silu=True), outs[0][1:2])
     w = _rand(3, 64, 3, 3, seed=101, scale=0.05)
     x = _rand(1, 64, H, W, seed=102)
     _close(_run_conv(x, w, 0), _conv_ref(x, w), what="small-cout plain 64->3")
