@@ -76,6 +76,16 @@ def run(cin, cout, hw, B, res=True, clock_ghz=0.1):
         d = "" if prev is None else f"   (+{m - prev:5.2f})"
         print(f"      {NAMES[k]:26s} {f:7.2f} {m:7.2f} {l:7.2f}{d}")
         prev = m
+    if os.environ.get("BF3_TIMELINE_PER_WAVE"):
+        # is it always the same wave that arrives last?  Per wave (= Winograd position): median over workgroups of its time at a
+        # stamp minus the workgroup's median wave at that stamp, and how often it is the workgroup's last wave there
+        for k in (3, 4, 7, 8):
+            col = rel[:, :, k]
+            off = (col - col.median(dim=1, keepdim=True).values).median(dim=0).values
+            last = torch.nn.functional.one_hot(col.argmax(dim=1), 16).double().mean(dim=0)
+            print(f"    {NAMES[k]}: per wave, us after the workgroup's median wave / share of workgroups where it is last")
+            print("      " + " ".join(f"{off[w]:+5.2f}" for w in range(16)))
+            print("      " + " ".join(f"{last[w]:5.2f}" for w in range(16)))
     life = (t[:, :, 15].max(dim=1).values - t[:, :, 0].min(dim=1).values) * tick_us
     grid = min(nwg, 256)
     if nwg > grid and os.environ.get("SISIC_BF3_PERSISTENT", "1") != "0":
