@@ -342,7 +342,12 @@ def main():
     # warm-up: W untimed steps (also sizes the library workspace)
     if W > 0:
         sched, x_T, z = make_run(W)
-        run_sampling_loop(model, sched, x_T, z)
+        warm = run_sampling_loop(model, sched, x_T, z)
+        if world > 1:
+            # the collectives of the timed region once, untimed: RCCL builds its point-to-point connections on first use
+            # (hundreds of milliseconds -- more than a 20-step run), and the all-reduce of the timing as well
+            sdist.gather_images(warm.images, B * world, dst=0)
+            sdist.max_over_ranks(0.0, dev)
     sched, x_T, z = make_run(K)
     barrier()
     t0 = time.perf_counter()
