@@ -33,7 +33,7 @@ extern "C" {
 /* 2 (round 4): sisic_sample_frames added; the packed-filter buffers grew in round 3 (1x1: three layouts = 3.5 x the
  * [Cin_pad][1][Cout_pad] floats; Winograd: the f32 U plus the bf16x3 split of it) -- ALWAYS size them with the *_numel
  * functions below, never from the layout comment. */
-#define SISIC_ABI_VERSION 2
+#define SISIC_ABI_VERSION 3
 
 #define SISIC_OK 0
 #define SISIC_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -97,7 +97,22 @@ typedef struct sisic_conv_args {
                                 that follows needs sisic_groupnorm_finalize only (no second pass over `out`).
                                 slots = sisic_conv_stats_slots(args); 0 there means "not available for this
                                 launch" and stats_out must stay NULL                                          */
+    /* Optional (ABI 3): the launch also FINALIZES the GroupNorm that reads its output alone -- groups over Cout, the module's
+     * gamma / beta -- and leaves that layer's (scale, shift) [B,Cout] (what sisic_groupnorm_finalize would compute from
+     * stats_out, bit for bit), so that no finalisation launch follows.  Only where sisic_conv_finalizes(args) says so
+     * (today: the K-split 8x8-level forms with 8 channels per group); elsewhere the fields are ignored.                */
+    const float* fin_gamma;  /* dev [Cout] or NULL (NULL: none of this)   */
+    const float* fin_beta;   /* dev [Cout]                                */
+    int fin_groups;
+    float fin_eps;
+    float* fin_scale;        /* dev [B,Cout] out                          */
+    float* fin_shift;        /* dev [B,Cout] out                          */
+    float* fin_mean_rstd;    /* dev [B,groups,2] out or NULL              */
 } sisic_conv_args;
+
+/* 1 when sisic_conv2d(args) with fin_gamma set will write fin_scale / fin_shift, 0 when the kernel selected for these
+ * arguments does not (the caller then runs sisic_groupnorm_finalize on stats_out as before).                          */
+int sisic_conv_finalizes(const sisic_conv_args* args);
 
 /* Number of partial-statistics slots per (image, output channel) that sisic_conv2d(args) writes to
  * args->stats_out, or 0 when the kernel selected for these arguments does not produce them.      */

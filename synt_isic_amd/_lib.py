@@ -14,7 +14,7 @@ _LIB_PATH = os.environ.get("SISIC_LIB_PATH") or os.path.join(os.path.dirname(os.
                                                              "libsisic_hip.so")
 _lib: Optional[C.CDLL] = None
 
-ABI_VERSION = 2          # include/sisic.h SISIC_ABI_VERSION
+ABI_VERSION = 3          # include/sisic.h SISIC_ABI_VERSION
 
 SISIC_OK = 0
 SISIC_EINVAL = -1
@@ -40,6 +40,8 @@ class ConvArgs(C.Structure):
         ("out", C.c_void_p), ("tile_cfg", C.c_int),
         ("w_winograd", C.c_void_p),
         ("stats_out", C.c_void_p),
+        ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_groups", C.c_int), ("fin_eps", C.c_float),
+        ("fin_scale", C.c_void_p), ("fin_shift", C.c_void_p), ("fin_mean_rstd", C.c_void_p),
     ]
 
 
@@ -67,6 +69,7 @@ SIGNATURES = {
     "sisic_conv_winograd_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "sisic_conv2d": (C.c_int, [C.c_void_p, C.POINTER(ConvArgs), C.c_void_p]),
     "sisic_conv_stats_slots": (C.c_int, [C.POINTER(ConvArgs)]),
+    "sisic_conv_finalizes": (C.c_int, [C.POINTER(ConvArgs)]),
     "sisic_groupnorm_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),

@@ -133,6 +133,7 @@ int sisic_conv2d(sisic_ctx* ctx, const sisic_conv_args* args, void* stream) {
 }
 
 int sisic_conv_stats_slots(const sisic_conv_args* args) { return args ? conv_stats_slots(*args) : 0; }
+int sisic_conv_finalizes(const sisic_conv_args* args) { return args && conv_finalizes(*args) ? 1 : 0; }
 
 int sisic_groupnorm_finalize(sisic_ctx* ctx, const float* stats0, int c0, int slots0, const float* stats1, int c1,
                              int slots1, int B, int HW, int groups, float eps, const float* gamma, const float* beta,

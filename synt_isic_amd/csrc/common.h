@@ -145,6 +145,7 @@ int launch_add_relu(sisic_ctx*, const float* y, const float* identity, float* ou
 int launch_gradcam(sisic_ctx*, const float* y, const float* outp, const float* fc_w, const float* bias, float* cam, int B, int C,
                    int h, int w, int S, int target, hipStream_t s);
 int conv_stats_slots(const sisic_conv_args& a);
+bool conv_finalizes(const sisic_conv_args& a);       // the launch leaves the following GroupNorm's (scale, shift) itself (sisic.h)
 // conv_pointwise.hip: the lean 1x1 kernel (tile_cfg 20)
 bool conv_pointwise_applicable(const sisic_conv_args& a);
 int conv_pointwise_stats_slots(const sisic_conv_args& a);

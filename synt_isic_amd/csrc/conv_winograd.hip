@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gn_merge.h"
 #include "pack_device.h"
 
 // Timing-only ablation builds for tools/conv_bench.py (results are wrong): bit 0 skips the MFMAs, bit 1 the
@@ -837,10 +838,25 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // The same reduction for planes of exactly 64 pixels (the 8x8 level: every launch of the headline model) with 16 lanes per plane
 // and 16-byte accesses: a quarter of the waves and of the memory instructions.  Output values: the same sums in the same order,
 // bit for bit; the GroupNorm partials are summed over another tree (four values per lane, then a 16-lane butterfly).
+// FIN (round 4): the launch also finalizes the GroupNorm over its own output when a group is EIGHT channels (the 8x8 level's 256
+// channels in 32 groups): a workgroup's 16 planes are two whole groups, so the partials of a group meet in LDS and every
+// channel's thread merges them -- in the order and with the operations of gn_finalize_kernel (gn_merge.h: the same bits) --
+// and writes its (scale, shift).  One 5 us launch less per such GroupNorm.
+__device__ __forceinline__ bool valid_wg(unsigned wg, int planes) { return (int)(wg * 16u) < planes; }
+struct ReduceFin {
+    const float* gamma;
+    const float* beta;
+    float* scale;
+    float* shift;
+    float* mean_rstd;
+    int groups;
+    float eps;
+};
+template <bool FIN>
 __global__ void __launch_bounds__(256) splitk_reduce64_kernel(const float4* __restrict__ part, int planes, int Cout,
                                                               const float* __restrict__ bias, const float* __restrict__ chan_bias,
                                                               int chan_bias_stride, const float4* residual, int relu,   // (out may alias residual)
-                                                              float4* out, float4* __restrict__ stats) {
+                                                              float4* out, float4* __restrict__ stats, const ReduceFin fin) {
     const int plane_raw = blockIdx.x * 16 + (threadIdx.x >> 4), l16 = threadIdx.x & 15;
     const bool valid = plane_raw < planes;               // (a row without a plane runs along on plane 0: the butterflies need every lane)
     const int plane = valid ? plane_raw : 0;
@@ -872,6 +888,46 @@ __global__ void __launch_bounds__(256) splitk_reduce64_kernel(const float4* __re
         for (int e = 0; e < 4; ++e) { const float d = a[e] - mean; m2 += d * d; }
         m2 = row16_sum(m2);
         if (valid && l16 == 0) stats[plane] = make_float4(64.0f, s1, m2, 0.0f);
+    }
+    if constexpr (FIN) {
+        // (launcher: Cout a multiple of 16 -- a workgroup's planes are one image's channels co0 .. co0 + 15 -- and 8 channels per group)
+        __shared__ float2 part_sm[16];
+        const float s1 = row16_sum((a[0] + a[1]) + (a[2] + a[3]));          // (as above: the partial this plane would leave)
+        const float mean_p = s1 * (1.0f / 64.0f);
+        float m2 = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = a[e] - mean_p; m2 += d * d; }
+        m2 = row16_sum(m2);
+        const int row = threadIdx.x >> 4;
+        if (l16 == 0) part_sm[row] = make_float2(s1, m2);
+        __syncthreads();
+        if (threadIdx.x < 16 && valid_wg(blockIdx.x, planes)) {
+            const int ch = threadIdx.x, g8 = ch >> 3;
+            // gn_finalize_kernel's lanes 0 .. 7 hold the group's eight partials and sum them through its 64-lane butterfly:
+            // ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)), in float64
+            double pn[8], ps[8], pm[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { pn[i] = (double)64.0f + (double)0.0f; ps[i] = (double)part_sm[8 * g8 + i].x + (double)0.0f; pm[i] = (double)part_sm[8 * g8 + i].y + (double)0.0f; }
+            auto tree = [](const double (&v)[8]) { return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])); };
+            const double n = tree(pn), sum1 = tree(ps), sum2 = tree(pm);
+            const double mean = sum1 / n;
+            double bt[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bt[i] = 0.0 + gn_between_term(64.0f, part_sm[8 * g8 + i].x, mean);
+            const double between = tree(bt);
+            float meanf, rstd;
+            gn_mean_rstd(n, sum1, sum2, between, fin.eps, meanf, rstd, mean);
+            const int plane0 = blockIdx.x * 16, b = plane0 / Cout, co = plane0 % Cout + ch;
+            float sc, sh;
+            gn_affine(fin.gamma[co], fin.beta[co], meanf, rstd, sc, sh);
+            fin.scale[(size_t)b * Cout + co] = sc;
+            fin.shift[(size_t)b * Cout + co] = sh;
+            if (fin.mean_rstd && (ch & 7) == 0) {
+                const int g = co >> 3;
+                fin.mean_rstd[2 * ((size_t)b * fin.groups + g)] = meanf;
+                fin.mean_rstd[2 * ((size_t)b * fin.groups + g) + 1] = rstd;
+            }
+        }
     }
 }
 
@@ -1069,11 +1125,22 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
         }
         const bool al16 = ((reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.out) |
                             reinterpret_cast<uintptr_t>(a.stats_out)) & 15) == 0;
-        if (HW == 64 && al16)
-            hipLaunchKernelGGL(splitk_reduce64_kernel, dim3((unsigned)((planes + 15) / 16)), dim3(256), 0, s,
-                               reinterpret_cast<const float4*>(scratch), (int)planes, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride,
-                               reinterpret_cast<const float4*>(a.residual), a.relu, reinterpret_cast<float4*>(a.out),
-                               reinterpret_cast<float4*>(a.stats_out));
+        if (HW == 64 && al16) {
+            const bool fin = conv_finalizes(a);
+            const ReduceFin rf{a.fin_gamma, a.fin_beta, a.fin_scale, a.fin_shift, a.fin_mean_rstd, a.fin_groups, a.fin_eps};
+            if (fin) {
+                SISIC_REQUIRE(a.fin_beta && a.fin_scale && a.fin_shift, "conv2d: fin_gamma given without fin_beta / fin_scale / fin_shift");
+                hipLaunchKernelGGL(splitk_reduce64_kernel<true>, dim3((unsigned)((planes + 15) / 16)), dim3(256), 0, s,
+                                   reinterpret_cast<const float4*>(scratch), (int)planes, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride,
+                                   reinterpret_cast<const float4*>(a.residual), a.relu, reinterpret_cast<float4*>(a.out),
+                                   reinterpret_cast<float4*>(a.stats_out), rf);
+            } else {
+                hipLaunchKernelGGL(splitk_reduce64_kernel<false>, dim3((unsigned)((planes + 15) / 16)), dim3(256), 0, s,
+                                   reinterpret_cast<const float4*>(scratch), (int)planes, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride,
+                                   reinterpret_cast<const float4*>(a.residual), a.relu, reinterpret_cast<float4*>(a.out),
+                                   reinterpret_cast<float4*>(a.stats_out), rf);
+            }
+        }
         else
             hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, scratch,
                                (int)planes, (int)HW, a.Cout, a.bias, a.chan_bias, a.chan_bias_stride, a.residual, a.relu,

@@ -13,6 +13,7 @@
 //
 // HBM-bound.  Algorithmic bytes per launch: 4*B*C*HW (read once) + 8*B*C (written).
 #include "common.h"
+#include "gn_merge.h"
 
 namespace sisic {
 
@@ -199,36 +200,30 @@ __global__ void __launch_bounds__(64 * GNF_WAVES) gn_finalize_kernel(const float
     m2 = wave64_sum_f64(m2);
     const double mean = s1 / n;
     double between = 0.0;
-    // n_i (mean_i - mean)^2 = (s1_i - n_i mean)^2 / n_i; n_i is a small integer, so its fp32 reciprocal (1 ulp) only
-    // perturbs this term by 1e-7 relative -- no float64 division per partial
-    auto dev = [&](const float4 v) {
-        if (v.x > 0.0f) {
-            const double d = (double)v.y - (double)v.x * mean;
-            between += d * d * (double)(1.0f / v.x);
-        }
-    };
+    auto dev = [&](const float4 v) { between += gn_between_term(v.x, v.y, mean); };       // (gn_merge.h)
 #pragma unroll
     for (int j = 0; j < KEEP; ++j) { dev(k0[j]); dev(k1[j]); }
     for (int i = lane + 64 * KEEP; i < len0; i += 64) dev(run0[i]);
     for (int i = lane + 64 * KEEP; i < len1; i += 64) dev(run1[i]);
     between = wave64_sum_f64(between);
-    const double var = fmax((m2 + between) / n, 0.0);
-    const float rstd = 1.0f / sqrtf((float)var + eps);
-    const float meanf = (float)mean;
+    float meanf, rstd;
+    gn_mean_rstd(n, s1, m2, between, eps, meanf, rstd, mean);
     if (mean_rstd && lane == 0) {
         mean_rstd[2 * (size_t)job] = meanf;
         mean_rstd[2 * (size_t)job + 1] = rstd;
     }
     if (lane < gs) {
-        const float sc = my_gamma * rstd;
+        float sc, sh;
+        gn_affine(my_gamma, my_beta, meanf, rstd, sc, sh);
         scale[(size_t)b * C + ca + lane] = sc;
-        shift[(size_t)b * C + ca + lane] = my_beta - meanf * sc;
+        shift[(size_t)b * C + ca + lane] = sh;
     }
     for (int cc = lane + 64; cc < gs; cc += 64) {
         const int c = ca + cc;
-        const float sc = gamma[c] * rstd;
+        float sc, sh;
+        gn_affine(gamma[c], beta[c], meanf, rstd, sc, sh);
         scale[(size_t)b * C + c] = sc;
-        shift[(size_t)b * C + c] = beta[c] - meanf * sc;
+        shift[(size_t)b * C + c] = sh;
     }
 }
 

@@ -359,6 +359,7 @@ struct Fwd {
 
     int gn(const Buf* x, const Buf* skip, const NormW& n) {
         gsc = u->gn_scale; gsh = u->gn_shift; gmr = nullptr; gnorm = &n;
+        if (!tr && !skip && x->fin_norm == static_cast<const void*>(&n)) return SISIC_OK;     // finalized by its producer (conv below)
         if (tr) {                 // this GroupNorm's own scale / shift / (mean, rstd): the backward pass needs them
             const int C = x->C + (skip ? skip->C : 0);
             SISIC_TRY(pool_get(u, (size_t)B * C, &gsc));
@@ -378,7 +379,7 @@ struct Fwd {
     int conv(const ConvW& c, const float* in0, int c0, const float* in1, int c1, int H, int W, int stride, int ups,
              bool gn_prologue, bool silu, const float* chan_bias, const float* residual, float* out,
              Buf* normed_later = nullptr, Buf* xb = nullptr, Buf* skipb = nullptr, Buf* resb = nullptr, Buf* outb = nullptr,
-             const AttnW* qkv_of = nullptr) {
+             const AttnW* qkv_of = nullptr, const NormW* next_norm = nullptr) {
         sisic_conv_args a{};
         a.in0 = in0; a.c0 = c0; a.in1 = in1; a.c1 = c1;
         a.B = B; a.Hin = H; a.Win = W; a.upsample = ups; a.ksize = c.k; a.stride = stride;
@@ -406,6 +407,15 @@ struct Fwd {
                 a.stats_out = normed_later->stats;
             }
         }
+        // next_norm: the GroupNorm that reads this output ALONE, when the caller knows it: where the launch can finalize it
+        // (sisic_conv_finalizes: the 8x8 level's K-split forms) it leaves that layer's (scale, shift) in the shared pair -- which
+        // this very convolution's prologue may still be reading: the finalisation runs in the reduction launch behind it
+        if (normed_later && next_norm && u->fuse_gn && !tr) {
+            a.fin_gamma = next_norm->gamma; a.fin_beta = next_norm->beta; a.fin_groups = u->cfg.norm_groups; a.fin_eps = u->cfg.norm_eps;
+            a.fin_scale = u->gn_scale; a.fin_shift = u->gn_shift;
+            if (conv_finalizes(a)) normed_later->fin_norm = next_norm;
+            else { a.fin_gamma = nullptr; a.fin_beta = nullptr; a.fin_scale = nullptr; a.fin_shift = nullptr; }
+        }
         if (tr) {
             TapeOp op;
             op.kind = TapeOp::CONV;
@@ -421,7 +431,9 @@ struct Fwd {
     }
 
     // out = ResnetBlock2D(cat(x, skip)); consumes nothing (caller releases inputs)
-    int resnet(const ResnetW& r, const Buf* x, const Buf* skip, Buf** out) {
+    // next_norm: the GroupNorm module that reads the block's output alone, when the caller knows it (conv(): finalized by conv2's
+    // own launch where that is possible)
+    int resnet(const ResnetW& r, const Buf* x, const Buf* skip, Buf** out, const NormW* next_norm = nullptr) {
         int rc = SISIC_OK;
         const int H = x->H, W = x->W;
         const int c1 = skip ? skip->C : 0;
@@ -429,7 +441,7 @@ struct Fwd {
         SISIC_TRY(gn(x, skip, r.norm1));
         Buf* h = make(r.cout, H, W, &rc); SISIC_TRY(rc);
         SISIC_TRY(conv(r.conv1, x->p, x->C, skip ? skip->p : nullptr, c1, H, W, 1, 0, true, true,
-                       tproj + r.temb_off, nullptr, h->p, h, const_cast<Buf*>(x), const_cast<Buf*>(skip), nullptr, h));
+                       tproj + r.temb_off, nullptr, h->p, h, const_cast<Buf*>(x), const_cast<Buf*>(skip), nullptr, h, nullptr, &r.norm2));
         const float* residual = x->p;
         Buf* resb = const_cast<Buf*>(x);
         Buf* sc = nullptr;
@@ -445,7 +457,7 @@ struct Fwd {
         SISIC_TRY(gn(h, nullptr, r.norm2));
         Buf* o = make(r.cout, H, W, &rc); SISIC_TRY(rc);
         SISIC_TRY(conv(r.conv2, h->p, r.cout, nullptr, 0, H, W, 1, 0, true, true, nullptr, residual, o->p, o, h, nullptr,
-                       resb, o));
+                       resb, o, nullptr, next_norm));
         release(h);
         release(sc);
         *out = o;
@@ -493,7 +505,10 @@ struct Fwd {
         for (int i = 0; i < n; ++i) {
             for (int j = 0; j < cfg.layers_per_block; ++j) {
                 Buf* y = nullptr;
-                SISIC_TRY(resnet(u->down_res[i][j], x, nullptr, &y));
+                // who normalises this block's output next (alone: the up path's concatenations have two producers)
+                const NormW* next = cfg.down_attn[i] ? &u->down_attn[i][j].norm
+                                    : (j + 1 < cfg.layers_per_block ? &u->down_res[i][j + 1].norm1 : (i == n - 1 ? &u->mid_res[0].norm1 : nullptr));
+                SISIC_TRY(resnet(u->down_res[i][j], x, nullptr, &y, next));
                 release(x);
                 x = y;
                 if (cfg.down_attn[i]) {
@@ -518,7 +533,7 @@ struct Fwd {
 
         {
             Buf* y = nullptr;
-            SISIC_TRY(resnet(u->mid_res[0], x, nullptr, &y)); release(x); x = y;
+            SISIC_TRY(resnet(u->mid_res[0], x, nullptr, &y, &u->mid_attn.norm)); release(x); x = y;
             SISIC_TRY(attention(u->mid_attn, x, &y)); release(x); x = y;
             SISIC_TRY(resnet(u->mid_res[1], x, nullptr, &y)); release(x); x = y;
         }

@@ -57,6 +57,8 @@ struct Buf {
     int refs = 0;
     float* stats = nullptr;   // GroupNorm partials written by the producing convolution (sisic_conv_args.stats_out)
     int slots = 0;
+    const void* fin_norm = nullptr;   // the GroupNorm module whose (scale, shift) the producing convolution has already left in the
+                                      // shared pair (sisic_conv_args.fin_*): its finalisation launch is skipped
 };
 
 struct PoolBlock {

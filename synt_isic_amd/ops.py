@@ -72,10 +72,12 @@ def pack_winograd_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bias=None, x2=None, stride=1,
            upsample=False, gn_scale=None, gn_shift=None, gn_silu=False, chan_bias=None, residual=None,
-           relu=False, tile_cfg=0, w_winograd=None, with_stats=False, out=None):
+           relu=False, tile_cfg=0, w_winograd=None, with_stats=False, out=None, finalize=None):
     """sisic_conv2d.  with_stats=True also returns the GroupNorm partials the epilogue wrote, as a
     [B, Cout, slots, 4] tensor of (count, sum, centred M2, 0), or None when this launch cannot produce them
-    (sisic_conv_stats_slots() == 0).  ``out``: the output tensor to write (it may be ``residual`` itself: include/sisic.h)."""
+    (sisic_conv_stats_slots() == 0).  ``out``: the output tensor to write (it may be ``residual`` itself: include/sisic.h).
+    ``finalize=(gamma, beta, groups, eps)``: ask the launch to finalize the GroupNorm over its own output as well; the result
+    then ends with ``(scale, shift)`` [B, Cout] tensors, or ``None`` where sisic_conv_finalizes() says this launch does not."""
     lib = _lib.load()
     B, c0, H, W = x.shape
     c1 = 0 if x2 is None else x2.shape[1]
@@ -103,8 +105,20 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, cout: int, ksize: int, *, bi
         if slots > 0:
             stats = torch.empty((B, cout, slots, 4), dtype=torch.float32, device=x.device)
             a.stats_out = stats.data_ptr()
+    fin = None
+    if finalize is not None:
+        gamma, beta, groups, eps = finalize
+        a.fin_gamma = _ptr(gamma, "gamma"); a.fin_beta = _ptr(beta, "beta"); a.fin_groups = int(groups); a.fin_eps = float(eps)
+        if lib.sisic_conv_finalizes(C.byref(a)):
+            fin = (torch.empty((B, cout), dtype=torch.float32, device=x.device), torch.empty((B, cout), dtype=torch.float32, device=x.device))
+            a.fin_scale, a.fin_shift = fin[0].data_ptr(), fin[1].data_ptr()
+        else:
+            a.fin_gamma = None
     check(lib.sisic_conv2d(context(x.device), C.byref(a), _stream(x.device)))
-    return (out, stats) if with_stats else out
+    res = (out, stats) if with_stats else out
+    if finalize is not None:
+        res = (res + (fin,)) if with_stats else (res, fin)
+    return res
 
 
 def groupnorm_finalize(stats: torch.Tensor, hw: int, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float,

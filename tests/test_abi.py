@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_channel(lib):
-    assert lib.sisic_abi_version() == 2          # include/sisic.h: 2 since sisic_sample_frames and the grown packed filters
+    assert lib.sisic_abi_version() == 3          # include/sisic.h: 3 since sisic_conv_args.fin_* / sisic_conv_finalizes (2: sisic_sample_frames, grown packed filters)
     # argument validation needs no GPU: NULL out-pointer is rejected with a message
     rc = lib.sisic_create(0, None)
     assert rc == -1
@@ -52,6 +52,7 @@ def test_struct_layout_matches_header():
     from synt_isic_amd import _lib
     P, I, F = ctypes.sizeof(ctypes.c_void_p), ctypes.sizeof(ctypes.c_int), ctypes.sizeof(ctypes.c_float)
     assert P == 8 and I == 4
-    assert ctypes.sizeof(_lib.ConvArgs) == 160
+    assert ctypes.sizeof(_lib.ConvArgs) == 208          # 160 + the ABI-3 fin_* fields: 2 pointers, int, float, 3 pointers
+    assert _lib.ConvArgs.fin_gamma.offset == 160 and _lib.ConvArgs.fin_groups.offset == 176 and _lib.ConvArgs.fin_eps.offset == 180 and _lib.ConvArgs.fin_scale.offset == 184 and _lib.ConvArgs.fin_mean_rstd.offset == 200
     assert _lib.ConvArgs.w_packed.offset == 48 and _lib.ConvArgs.out.offset == 128 and _lib.ConvArgs.w_winograd.offset == 144 and _lib.ConvArgs.stats_out.offset == 152
     assert ctypes.sizeof(_lib.UNetConfigC) == 4 * 4 + 3 * 32 + 4 * 4 + 8

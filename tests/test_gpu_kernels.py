@@ -1099,3 +1099,36 @@ def test_conv_residual_may_alias_out(cfg, k, ups, B, H, W, cin, cout):
     assert got.data_ptr() == buf.data_ptr()
     assert torch.equal(got, want), f"cfg{cfg}: in-place accumulate differs from the out-of-place result"
     _close(got, _conv_ref(x, w, b, upsample=ups, stride=stride, residual=res), what=f"in-place conv cfg{cfg}")
+
+
+def test_conv_finalizes_its_own_groupnorm_at_the_8x8_level():
+    """ABI 3, sisic_conv_args.fin_*: the K-split 8x8-level convolution (tile_cfg 92 / auto) leaves the (scale, shift) of the
+    GroupNorm over its own output -- bit for bit what sisic_groupnorm_finalize computes from the partials it also leaves --
+    and sisic_conv_finalizes() says where it does not (another level, another group size)."""
+    from synt_isic_amd import ops
+    d = lambda t: t.to(DEV).contiguous()
+    B, cin, cout = 5, 128, 256
+    x = _rand(B, cin, 8, 8, seed=700)
+    w = _rand(cout, cin, 3, 3, seed=701, scale=(9 * cin) ** -0.5)
+    b, res = _rand(cout, seed=702), _rand(B, cout, 8, 8, seed=703)
+    gamma, beta = 1.0 + 0.1 * _rand(cout, seed=704), 0.1 * _rand(cout, seed=705)
+    gn = (1.0 + 0.3 * _rand(B, cin, seed=706), 0.3 * _rand(B, cin, seed=707))
+    wp, ww = ops.pack_conv_weight(d(w)), ops.pack_winograd_weight(d(w))
+    for cfg in (0, 92, 91):
+        y, st, fin = ops.conv2d(d(x), wp, cout, 3, bias=d(b), residual=d(res), gn_scale=d(gn[0]), gn_shift=d(gn[1]), gn_silu=True,
+                                tile_cfg=cfg, w_winograd=ww, with_stats=True, finalize=(d(gamma), d(beta), 32, 1e-5))
+        assert fin is not None and st is not None
+        sc, sh = ops.groupnorm_finalize(st, 64, d(gamma), d(beta), 32, 1e-5)
+        assert torch.equal(fin[0], sc) and torch.equal(fin[1], sh), f"cfg {cfg}"
+        yc = y.cpu().double()
+        ref = F.group_norm(yc, 32, gamma.double(), beta.double(), 1e-5)
+        _close((yc * fin[0].cpu().double()[:, :, None, None] + fin[1].cpu().double()[:, :, None, None]).float(), ref, what="fused finalisation")
+        # the same output as without the request
+        assert torch.equal(y, ops.conv2d(d(x), wp, cout, 3, bias=d(b), residual=d(res), gn_scale=d(gn[0]), gn_shift=d(gn[1]), gn_silu=True,
+                                         tile_cfg=cfg, w_winograd=ww))
+    # 16 groups of 16 channels, or a 16x16 plane: not finalized by the launch
+    _, fin = ops.conv2d(d(x), wp, cout, 3, w_winograd=ww, finalize=(d(gamma), d(beta), 16, 1e-5))
+    assert fin is None
+    x16 = _rand(2, cin, 16, 16, seed=708)
+    _, fin = ops.conv2d(d(x16), wp, cout, 3, w_winograd=ww, finalize=(d(gamma), d(beta), 32, 1e-5))
+    assert fin is None
