@@ -554,14 +554,18 @@ int conv_stats_slots(const sisic_conv_args& a) {
     return slots;
 }
 
-// sisic_conv_finalizes(): the K-split 8x8-level forms sum their partial slabs in a kernel whose workgroup holds 16 whole channel
-// planes of an image -- two whole GroupNorm groups of eight channels -- and finalize them there (conv_winograd.hip, ReduceFin)
+// sisic_conv_finalizes(): where a workgroup holds whole GroupNorm groups (eight channels) of an image it finalizes them: the
+// K-split 8x8-level forms in their reduction kernel (16 whole channel planes per workgroup: conv_winograd.hip, ReduceFin), the
+// bf16x3 Winograd kernel where one tile is the whole image (16x16 and smaller: conv_winograd_bf3.inc)
 bool conv_finalizes(const sisic_conv_args& a) {
     if (!a.fin_gamma || a.fin_groups <= 0) return false;
     const int cfg = winograd_cfg(a);
-    if (cfg < 90 || cfg > 92) return false;
     const int Hout = a.Hin << (a.upsample ? 1 : 0), Wout = a.Win << (a.upsample ? 1 : 0);
-    if (Hout * Wout != 64 || a.Cout % 16 != 0 || a.Cout % a.fin_groups != 0 || a.Cout / a.fin_groups != 8) return false;
+    if (a.Cout % a.fin_groups != 0 || a.Cout / a.fin_groups != 8) return false;
+    // the bf16x3 Winograd kernel where ONE 16x16-pixel tile is the whole image: a workgroup holds 64 channels of an image whole
+    if (cfg == 74) return !a.upsample && Hout <= 16 && Wout <= 16 && a.Cout % 64 == 0;
+    if (cfg < 90 || cfg > 92) return false;
+    if (Hout * Wout != 64 || a.Cout % 16 != 0) return false;
     // (the 16-byte form of the reduction; its scratch slabs are the library's own allocation)
     return ((reinterpret_cast<uintptr_t>(a.residual) | reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.stats_out)) & 15) == 0;
 }

@@ -75,6 +75,15 @@ struct WinoParams {
     int ksplit;         // workgroups per output tile, each covering nchunks/ksplit channel chunks (1 = no split)
     int groups_x, groups_y, groups_b, n_co_tiles, nwg, nchunks;
     int stagger;        // 1: half of the waves run MFMA-first, the other half stage-first (see the channel loop)
+    // sisic_conv_args.fin_*: where a workgroup holds a whole image of its channels (conv_winograd_bf3.inc, one tile per image) it
+    // finalizes the following GroupNorm's groups of eight channels itself (fin_gamma == nullptr: not requested / not possible)
+    const float* fin_gamma;
+    const float* fin_beta;
+    float* fin_scale;
+    float* fin_shift;
+    float* fin_mean_rstd;
+    int fin_groups;
+    float fin_eps;
 };
 
 constexpr int W_CIC = 8;            // input channels per chunk
@@ -1042,6 +1051,11 @@ int launch_conv_winograd(sisic_ctx* ctx, const sisic_conv_args& a, const float* 
     p.stagger = ((cfg >= 64 && cfg <= 67) || cfg == 90) ? 1 : 0;
     p.ksplit = 1;
     static const bool col_default = [] { const char* e = std::getenv("SISIC_WINO_COL"); return !e || std::atoi(e) != 0; }();
+    if (cfg == 74 && conv_finalizes(a)) {       // (one 16x16-pixel tile per image: conv_mfma.hip)
+        SISIC_REQUIRE(a.fin_beta && a.fin_scale && a.fin_shift, "conv2d: fin_gamma given without fin_beta / fin_scale / fin_shift");
+        p.fin_gamma = a.fin_gamma; p.fin_beta = a.fin_beta; p.fin_scale = a.fin_scale; p.fin_shift = a.fin_shift;
+        p.fin_mean_rstd = a.fin_mean_rstd; p.fin_groups = a.fin_groups; p.fin_eps = a.fin_eps;
+    }
     if (cfg == 74) {                // fp32-equivalent products on the bf16 pipe (conv_winograd_bf3.inc)
         // (a nearest-2x input is read through the staging plan's addresses: all 16 positions are multiplied, where the f32
         //  upsample form multiplies 9 -- which of the two is faster depends on the plane, conv_mfma.hip)

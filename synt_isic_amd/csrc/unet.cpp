@@ -299,6 +299,8 @@ int ensure_rows(sisic_unet* u, size_t t_rows, size_t gn_rows) {
     SISIC_TRY(grow(&u->tproj, &u->tproj_cap, t_rows * u->tproj_R));
     SISIC_TRY(grow(&u->gn_scale, &u->gn_scale_cap, gn_rows * u->max_c));
     SISIC_TRY(grow(&u->gn_shift, &u->gn_shift_cap, gn_rows * u->max_c));
+    SISIC_TRY(grow(&u->gn_scale2, &u->gn_scale2_cap, gn_rows * u->max_c));
+    SISIC_TRY(grow(&u->gn_shift2, &u->gn_shift2_cap, gn_rows * u->max_c));
     return SISIC_OK;
 }
 
@@ -359,7 +361,10 @@ struct Fwd {
 
     int gn(const Buf* x, const Buf* skip, const NormW& n) {
         gsc = u->gn_scale; gsh = u->gn_shift; gmr = nullptr; gnorm = &n;
-        if (!tr && !skip && x->fin_norm == static_cast<const void*>(&n)) return SISIC_OK;     // finalized by its producer (conv below)
+        if (!tr && !skip && x->fin_norm == static_cast<const void*>(&n)) {     // finalized by its producer (conv below)
+            gsc = x->fin_scale; gsh = x->fin_shift;
+            return SISIC_OK;
+        }
         if (tr) {                 // this GroupNorm's own scale / shift / (mean, rstd): the backward pass needs them
             const int C = x->C + (skip ? skip->C : 0);
             SISIC_TRY(pool_get(u, (size_t)B * C, &gsc));
@@ -412,8 +417,11 @@ struct Fwd {
         // this very convolution's prologue may still be reading: the finalisation runs in the reduction launch behind it
         if (normed_later && next_norm && u->fuse_gn && !tr) {
             a.fin_gamma = next_norm->gamma; a.fin_beta = next_norm->beta; a.fin_groups = u->cfg.norm_groups; a.fin_eps = u->cfg.norm_eps;
-            a.fin_scale = u->gn_scale; a.fin_shift = u->gn_shift;
-            if (conv_finalizes(a)) normed_later->fin_norm = next_norm;
+            // (the pair this launch's own prologue is NOT reading: a workgroup finalizes its image while others still read theirs)
+            const bool first_pair_busy = gn_prologue && gsc == u->gn_scale;
+            a.fin_scale = first_pair_busy ? u->gn_scale2 : u->gn_scale;
+            a.fin_shift = first_pair_busy ? u->gn_shift2 : u->gn_shift;
+            if (conv_finalizes(a)) { normed_later->fin_norm = next_norm; normed_later->fin_scale = a.fin_scale; normed_later->fin_shift = a.fin_shift; }
             else { a.fin_gamma = nullptr; a.fin_beta = nullptr; a.fin_scale = nullptr; a.fin_shift = nullptr; }
         }
         if (tr) {
@@ -547,7 +555,9 @@ struct Fwd {
                 SISIC_REQUIRE(skip->H == x->H && skip->W == x->W, "unet: skip resolution %dx%d vs %dx%d (H and W must be divisible by %d)",
                               skip->H, skip->W, x->H, x->W, 1 << (n - 1));
                 Buf* y = nullptr;
-                SISIC_TRY(resnet(u->up_res[i][j], x, skip, &y));
+                // (the block's output is normalised alone only when an attention block follows; the next ResNet block normalises
+                //  it together with a skip tensor)
+                SISIC_TRY(resnet(u->up_res[i][j], x, skip, &y, cfg.up_attn[i] ? &u->up_attn[i][j].norm : nullptr));
                 release(x);
                 release(skip);
                 x = y;
@@ -673,7 +683,7 @@ int sisic_unet_destroy(sisic_unet* u) {
         if (p) (void)hipFree(p);
     if (u->loop_stream) (void)hipStreamDestroy(u->loop_stream);
     for (auto p : u->owned) (void)hipFree(p);
-    for (float* p : {u->raw, u->t_vals, u->temb_act, u->tproj, u->gn_scale, u->gn_shift, u->eps_buf})
+    for (float* p : {u->raw, u->t_vals, u->temb_act, u->tproj, u->gn_scale, u->gn_shift, u->gn_scale2, u->gn_shift2, u->eps_buf})
         if (p) (void)hipFree(p);
     if (u->stage_host) (void)hipHostFree(u->stage_host);
     for (auto e : u->stage_ev)

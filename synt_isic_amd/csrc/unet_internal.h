@@ -57,8 +57,9 @@ struct Buf {
     int refs = 0;
     float* stats = nullptr;   // GroupNorm partials written by the producing convolution (sisic_conv_args.stats_out)
     int slots = 0;
-    const void* fin_norm = nullptr;   // the GroupNorm module whose (scale, shift) the producing convolution has already left in the
-                                      // shared pair (sisic_conv_args.fin_*): its finalisation launch is skipped
+    const void* fin_norm = nullptr;   // the GroupNorm module whose (scale, shift) the producing convolution has already left in
+    float* fin_scale = nullptr;       // fin_scale / fin_shift (sisic_conv_args.fin_*): its finalisation launch is skipped
+    float* fin_shift = nullptr;
 };
 
 struct PoolBlock {
@@ -178,7 +179,9 @@ struct sisic_unet {
     float* tproj = nullptr;      // [B or T, tproj_R]
     float* gn_scale = nullptr;   // [B, max_c]
     float* gn_shift = nullptr;
-    size_t t_vals_cap = 0, temb_act_cap = 0, tproj_cap = 0, gn_scale_cap = 0, gn_shift_cap = 0;
+    float* gn_scale2 = nullptr;  // a second pair: a convolution that finalizes the GroupNorm of its own output (sisic_conv_args.fin_*)
+    float* gn_shift2 = nullptr;  //   writes the pair its own prologue is NOT reading (later workgroups of the launch still read that one)
+    size_t t_vals_cap = 0, temb_act_cap = 0, tproj_cap = 0, gn_scale_cap = 0, gn_shift_cap = 0, gn_scale2_cap = 0, gn_shift2_cap = 0;
     static constexpr int STAGE_SLOTS = 4;
     float* stage_host = nullptr; // pinned upload ring
     size_t stage_cap = 0;

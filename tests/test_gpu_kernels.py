@@ -1126,9 +1126,22 @@ def test_conv_finalizes_its_own_groupnorm_at_the_8x8_level():
         # the same output as without the request
         assert torch.equal(y, ops.conv2d(d(x), wp, cout, 3, bias=d(b), residual=d(res), gn_scale=d(gn[0]), gn_shift=d(gn[1]), gn_silu=True,
                                          tile_cfg=cfg, w_winograd=ww))
-    # 16 groups of 16 channels, or a 16x16 plane: not finalized by the launch
+    # 16 groups of 16 channels: not finalized by the launch
     _, fin = ops.conv2d(d(x), wp, cout, 3, w_winograd=ww, finalize=(d(gamma), d(beta), 16, 1e-5))
     assert fin is None
-    x16 = _rand(2, cin, 16, 16, seed=708)
-    _, fin = ops.conv2d(d(x16), wp, cout, 3, w_winograd=ww, finalize=(d(gamma), d(beta), 32, 1e-5))
-    assert fin is None
+    # a plane that is ONE 16x16-pixel tile of the bf16x3 Winograd kernel (tile_cfg 74): its workgroup holds 64 channels of an
+    # image whole and finalizes their eight groups; ragged planes too (16 x 14); two tiles (16 x 32) not
+    for (H, W, does) in ((16, 16, True), (16, 14, True), (16, 32, False)):
+        xs = _rand(3, cin, H, W, seed=708)
+        rs = _rand(3, cout, H, W, seed=709)
+        gs = (1.0 + 0.3 * _rand(3, cin, seed=710), 0.3 * _rand(3, cin, seed=711))
+        kw = dict(bias=d(b), residual=d(rs), gn_scale=d(gs[0]), gn_shift=d(gs[1]), gn_silu=True, w_winograd=ww)
+        y, st, fin = ops.conv2d(d(xs), wp, cout, 3, with_stats=True, finalize=(d(gamma), d(beta), 32, 1e-5), **kw)
+        assert (fin is not None) == does, (H, W)
+        if does:
+            sc, sh = ops.groupnorm_finalize(st, H * W, d(gamma), d(beta), 32, 1e-5)
+            assert torch.equal(fin[0], sc) and torch.equal(fin[1], sh), (H, W)
+            assert torch.equal(y, ops.conv2d(d(xs), wp, cout, 3, **kw))
+            # without stats_out as well
+            _, fin2 = ops.conv2d(d(xs), wp, cout, 3, finalize=(d(gamma), d(beta), 32, 1e-5), **kw)
+            assert torch.equal(fin2[0], sc) and torch.equal(fin2[1], sh)
