@@ -233,6 +233,35 @@ def test_oracle_classifier_matches_transformers_resnet():
                                    hf(pixel_values=ores.preprocess_for_classifier(x64)).logits, rtol=1e-5, atol=2e-5)
 
 
+def test_oracle_attention_block_matches_torch_multihead_attention():
+    """Independent pin of the attention block's arithmetic (oracle/unet.py attention_block; diffusers' Attention as configured at
+    model_manager.py:173-194: 32 heads x d = 8, GroupNorm in front, residual behind): torch's own nn.MultiheadAttention --
+    packed in-projection, contiguous channel runs per head, softmax(q k^T / sqrt(d)) v, out-projection -- assembled from the
+    same state-dict entries, with nn.GroupNorm in front.  Not the oracle's code path: a different implementation of the same
+    published block."""
+    import torch.nn as nn
+    from oracle import unet as ounet
+    sd = weights.synthetic_unet_state_dict()
+    for p, hw in (("mid_block.attentions.0", 8), ("down_blocks.2.attentions.1", 16)):
+        assert f"{p}.to_q.weight" in sd
+        C = sd[f"{p}.to_q.weight"].shape[0]
+        mha = nn.MultiheadAttention(C, C // ounet.HEAD_DIM, bias=True, batch_first=True).eval()
+        gn = nn.GroupNorm(ounet.NORM_GROUPS, C, eps=ounet.NORM_EPS).eval()
+        with torch.no_grad():
+            mha.in_proj_weight.copy_(torch.cat([sd[f"{p}.to_{n}.weight"] for n in "qkv"]))
+            mha.in_proj_bias.copy_(torch.cat([sd[f"{p}.to_{n}.bias"] for n in "qkv"]))
+            mha.out_proj.weight.copy_(sd[f"{p}.to_out.0.weight"])
+            mha.out_proj.bias.copy_(sd[f"{p}.to_out.0.bias"])
+            gn.weight.copy_(sd[f"{p}.group_norm.weight"])
+            gn.bias.copy_(sd[f"{p}.group_norm.bias"])
+            x = torch.randn(2, C, hw, hw, generator=torch.Generator().manual_seed(3))
+            tokens = gn(x).flatten(2).transpose(1, 2)                       # [B, N, C]
+            o, _ = mha(tokens, tokens, tokens, need_weights=False)
+            ref = o.transpose(1, 2).reshape(x.shape) + x
+            got = ounet.attention_block(sd, p, x)
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5)
+
+
 def test_product_does_not_import_oracle():
     import os
     import re
