@@ -347,6 +347,9 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwb_kernel(const PwbPa
 // split its input channels four ways (a quarter of the chain each, all in flight together), put their partial accumulators into
 // LDS, and each wave sums -- in the fixed order ((k0 + k1) + k2) + k3 -- and stores a quarter of the item's 64 channels.
 // Another summation order than the forms above: other bits, so the choice between them is by layer SHAPE only (launcher).
+#ifndef PWBK_VAR
+#define PWBK_VAR 0
+#endif
 template <int PRO>
 __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwbk_kernel(const PwbParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -410,7 +413,15 @@ __global__ void __launch_bounds__(64 * PWB_WAVES, 4) conv_pwbk_kernel(const PwbP
 #pragma unroll
         for (int x = 0; x < CB; ++x) {
             fa[x] = __builtin_amdgcn_raw_buffer_load_b128(rsw, a_lane16, s0 + 1024u * (unsigned)x, 0);
+#if (PWBK_VAR & 1) != 0           // timing-only builds (wrong results): bit 0 no U_lo fetch, bit 1 no filter fetch at all
+            fl[x] = pwb_u2{fa[x].z, fa[x].w};
+#else
             fl[x] = __builtin_amdgcn_raw_buffer_load_b64(rsw, a_lane8, s0 + 2048u + 512u * (unsigned)x, 0);
+#endif
+#if (PWBK_VAR & 2) != 0
+            fa[x] = pwb_u4{a_lane16 + (unsigned)c, a_lane8, s0, a_lane16 ^ s0};
+            fl[x] = pwb_u2{fa[x].z, fa[x].w};
+#endif
         }
     };
     struct Tup { pwb_u4 hm, mh, lh; };
