@@ -36,6 +36,17 @@ def test_launcher_two_ranks_dry_run_prints_one_line():
     assert "gather of 128 stand-in images" in r.stderr
 
 
+def test_launcher_eight_ranks_dry_run():
+    """the driver's largest case (`bench.py --gpus 8`): eight ranks rendezvous, shard 512 images, gather them, print ONE line"""
+    r = _run(["--gpus", "8", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 512 and d["config"]["batch_per_gpu"] == 64
+    assert "gather of 512 stand-in images" in r.stderr
+
+
 def test_single_rank_dry_run_has_the_same_schema():
     r = _run(["--dry-run"])
     assert r.returncode == 0, r.stderr[-2000:]
